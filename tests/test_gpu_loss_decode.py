@@ -1,0 +1,204 @@
+"""GPU parity: fused loss fwd+bwd, decoder, NMS, IoU helpers -- HIP (through the C-ABI)
+against the oracle and the golden vectors produced by the reference's modules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("case", load_cases("loss_cases.npz"), ids=lambda c: "S%d_N%d_%s" % (c["S"], c["N"], c["kind"]))
+def test_loss_golden(case, dev):
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    S, bs = int(case["S"]), int(case["bs"])
+    p = torch.tensor(case["pred"], device=dev, requires_grad=True)
+    t = torch.tensor(case["target"], device=dev)
+    layer = YOLOLossV1(bs, S, 2, 20, 5.0, 0.5, _device=str(dev), _quiet=True)
+    loss = layer(p, t)
+    loss.backward()
+    # tolerance: fp32 loss & grad <= 1e-5 rel / 1e-6 abs vs the reference
+    np.testing.assert_allclose(loss.item(), case["loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(layer.last_components.cpu().numpy(), case["comps"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), case["grad"], rtol=1e-5, atol=1e-6)
+
+
+def test_loss_permuted_pred_and_upstream_scale(dev):
+    from yolo_v1_amd.v1Loss import yoloLoss
+    c = load_cases("loss_cases.npz")[4]
+    S = int(c["S"])
+    base = torch.tensor(c["pred"], device=dev).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    p = base.permute(0, 2, 3, 1)                     # strides as the reference backbone returns them
+    assert not p.is_contiguous()
+    layer = yoloLoss(int(c["bs"]), S, 2, 20, _quiet=True)
+    loss = layer(p, torch.tensor(c["target"], device=dev))
+    (loss * 3.0).backward()
+    np.testing.assert_allclose(loss.item(), c["loss"], rtol=1e-5)
+    g = base.grad.permute(0, 2, 3, 1).cpu().numpy()
+    np.testing.assert_allclose(g, 3.0 * c["grad"], rtol=1e-5, atol=3e-6)
+
+
+def test_loss_full_size_vs_oracle_and_logging(dev):
+    # BASELINE config sizes: N=64, S=7 and S=14, encoder-made targets (3 objects per image)
+    from oracle import loss as ol
+    from oracle import train_step as ots
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    for S in (7, 14):
+        _, tg = ots.synthetic_batch(64, S, hw=8)
+        pred = torch.rand(64, S, S, 30, generator=torch.Generator().manual_seed(S)) * 0.96 + 0.02
+        ref_loss, ref_comps, ref_grad = ol.yolo_loss_and_grad(pred, tg, S, 2, 20, 5.0, 0.5, 64)
+        msgs = []
+
+        class L:
+            def info(self, m):
+                msgs.append(m)
+        layer = YOLOLossV1(64, S, 2, 20, _logger=L())
+        p = pred.to(dev).requires_grad_(True)
+        loss = layer(p, tg.to(dev))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref_grad, rtol=1e-5, atol=1e-6)
+        want = 'location loss : %.5f contain loss : %.5f not contain loss: %.5f classify loss : %.5f' % tuple(
+            (ref_comps / 64).tolist())
+        assert len(msgs) == 1 and msgs[0][:20] == want[:20]
+        # linearity property at full size: loss(pred, target; bs) * bs is batch-size independent
+        l2 = YOLOLossV1(128, S, 2, 20, _quiet=True)(p.detach(), tg.to(dev))
+        np.testing.assert_allclose(l2.item() * 2, loss.item(), rtol=1e-6)
+
+
+def test_loss_rejects_cpu_and_bad_shape(dev):
+    from yolo_v1_amd import _lib
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    layer = YOLOLossV1(1, 7, 2, 20, _quiet=True)
+    with pytest.raises(_lib.Yv1Error):
+        layer(torch.zeros(1, 7, 7, 30), torch.zeros(1, 7, 7, 30))
+    with pytest.raises(_lib.Yv1Error):
+        layer(torch.zeros(1, 7, 7, 29, device=dev), torch.zeros(1, 7, 7, 30, device=dev))
+
+
+# ------------------------------------------------------------------ IoU helpers
+def test_iou_and_convert_bit_exact(dev):
+    from yolo_v1_amd.utils.utils import compute_iou_matrix, convert_CxCyWH_to_X1Y1X2Y2
+    z = np.load(os.path.join(GOLDEN, "iou_cases.npz"))
+    t = lambda a: torch.tensor(a, device=dev)
+    np.testing.assert_array_equal(compute_iou_matrix(t(z["known_b1"]), t(z["known_b2"])).cpu().numpy(), z["known_iou"])
+    np.testing.assert_array_equal(compute_iou_matrix(t(z["r1"]), t(z["r2"])).cpu().numpy(), z["r_iou"])
+    np.testing.assert_array_equal(convert_CxCyWH_to_X1Y1X2Y2(t(z["cx"]), 7, 2, dev).cpu().numpy(), z["cx7"])
+    np.testing.assert_array_equal(convert_CxCyWH_to_X1Y1X2Y2(t(z["cx"]), 14, 2, dev).cpu().numpy(), z["cx14"])
+    with pytest.raises(AssertionError):
+        convert_CxCyWH_to_X1Y1X2Y2(torch.zeros(3, 5, device=dev), 7, 2, dev)
+
+
+# ------------------------------------------------------------------ NMS
+def test_nms_golden_bit_exact(dev):
+    from yolo_v1_amd.utils.utils import nms
+    for c in load_cases("nms_cases.npz"):
+        keep = nms(torch.tensor(c["boxes"], device=dev), torch.tensor(c["scores"], device=dev), float(c["thr"]))
+        assert keep.dtype == torch.int64
+        np.testing.assert_array_equal(keep.cpu().numpy(), c["keep"])
+
+
+def test_nms_random_vs_oracle_incl_single_survivor_and_edges(dev):
+    from oracle import boxes as obx
+    from yolo_v1_amd.utils.utils import nms
+    rng = np.random.RandomState(0)
+    for n in (1, 2, 3, 7, 63, 64, 65, 128, 129, 392, 500, 896):
+        for thr in (0.25, 0.45, 1.0):
+            xy = rng.uniform(0, 0.8, size=(n, 2))
+            wh = rng.uniform(0.02, 0.4, size=(n, 2))
+            b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+            s = rng.uniform(0, 1, size=n).astype(np.float32)
+            if n > 4:
+                s[3] = s[1]                      # exact score tie -> ascending index
+                b[2] = b[0]                      # duplicate box: IoU == 1
+                b[4, 2:] = b[4, :2]              # zero-area box
+            got = nms(torch.tensor(b, device=dev), torch.tensor(s, device=dev), thr).cpu().numpy()
+            np.testing.assert_array_equal(got, obx.nms(b, s, thr))
+    # all-degenerate: every pair 0/0 = NaN -> suppressed (only the top survives)
+    z = np.zeros((5, 4), np.float32)
+    s = np.array([.1, .5, .3, .2, .4], np.float32)
+    np.testing.assert_array_equal(nms(torch.tensor(z, device=dev), torch.tensor(s, device=dev), 0.5).cpu().numpy(),
+                                  obx.nms(z, s, 0.5))
+    assert nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev), 0.5).numel() == 0
+    # idempotence: NMS of the kept set keeps everything, in the same order
+    n = 392
+    xy = rng.uniform(0, 0.8, size=(n, 2)); wh = rng.uniform(0.02, 0.4, size=(n, 2))
+    bt = torch.tensor(np.concatenate([xy, xy + wh], 1).astype(np.float32), device=dev)
+    st = torch.tensor(rng.permutation(n).astype(np.float32) / n, device=dev)
+    k1 = nms(bt, st, 0.45)
+    k2 = nms(bt[k1], st[k1], 0.45)
+    np.testing.assert_array_equal(k2.cpu().numpy(), np.arange(k1.numel()))
+
+
+# ------------------------------------------------------------------ decoder
+def test_decoder_golden(dev):
+    from yolo_v1_amd.utils.utils import decode_batch, decoder
+    for c in load_cases("decoder_cases.npz"):
+        S = int(c["S"])
+        pred = torch.tensor(c["pred"], device=dev)
+        before = pred.clone()
+        # decode stage alone: nms threshold 1.0 keeps every candidate unless IoU > 1 / NaN; compare as sets by index
+        bx, cl, pr, keep, cnt, ncand = decode_batch(pred, S, 2, float(c["thresh"]), 1.0)
+        assert torch.equal(pred, before)                     # input not modified (T7 not reproduced)
+        if int(ncand[0]) == 0:
+            assert c["cand_boxes"].shape == (1, 4) and not c["cand_boxes"].any()
+        else:
+            assert int(ncand[0]) == c["cand_boxes"].shape[0]
+            k = int(cnt[0])
+            idx = keep[0, :k].cpu().numpy()
+            np.testing.assert_array_equal(bx[0, :k].cpu().numpy(), c["cand_boxes"][idx])
+            np.testing.assert_array_equal(cl[0, :k].cpu().numpy(), c["cand_cls"][idx])
+            np.testing.assert_array_equal(pr[0, :k].cpu().numpy(), c["cand_probs"][idx])
+        if int(c["full_ok"]):
+            fb, fc, fp = decoder(pred, grid_num=S, device=dev, thresh=float(c["thresh"]), nms_th=float(c["nms_th"]))
+            np.testing.assert_array_equal(fb.cpu().numpy(), c["full_boxes"])
+            np.testing.assert_array_equal(fc.cpu().numpy(), c["full_cls"])
+            np.testing.assert_array_equal(fp.cpu().numpy(), c["full_probs"])
+            assert fc.dtype == torch.int64
+
+
+def test_decoder_batched_full_size_vs_oracle(dev):
+    # N=64 images, S=7 and 14 (98 / 392 slots), mAP-run thresholds (utils/utils.py:405)
+    from oracle import boxes as obx
+    from yolo_v1_amd.utils.utils import decode_batch
+    for S in (7, 14):
+        g = torch.Generator().manual_seed(40 + S)
+        pred = torch.rand(64, S, S, 30, generator=g)
+        pred[..., :2] *= (torch.rand(64, S, S, 2, generator=g) > 0.6).float()
+        pred[5] = 0                                            # an image with zero candidates
+        bx, cl, pr, keep, cnt, ncand = decode_batch(pred.to(dev), S, 2, 0.005, 0.45)
+        bx, cl, pr, keep, cnt = bx.cpu().numpy(), cl.cpu().numpy(), pr.cpu().numpy(), keep.cpu().numpy(), cnt.cpu().numpy()
+        for n in range(64):
+            rb, rc, rp, rk = obx.decoder(pred[n].numpy(), S, 2, 0.005, 0.45)
+            k = int(cnt[n])
+            assert k == rb.shape[0]
+            np.testing.assert_array_equal(keep[n, :k], rk)     # kept-box indices bit-exact
+            np.testing.assert_array_equal(cl[n, :k], rc)
+            np.testing.assert_array_equal(bx[n, :k], rb)
+            np.testing.assert_array_equal(pr[n, :k], rp)
+        assert int(ncand[5]) == 0 and int(cnt[5]) == 1 and not bx[5, 0].any()
+
+
+def test_decoder_gt_mode_roundtrip_encode_decode(dev):
+    # encode -> decode(gt=True) round trip (what utils/YOLODataLoader.py:249 does visually)
+    from oracle import boxes as obx
+    from yolo_v1_amd.utils.utils import decoder
+    boxes = np.array([[0.21, 0.33, 0.2, 0.3], [0.77, 0.6, 0.1, 0.4], [0.5, 0.9, 0.3, 0.15]], np.float32)
+    tg = obx.encode_target(boxes, [3, 7, 11], 7)
+    b, c, p = decoder(torch.tensor(tg, device=dev)[None], grid_num=7, device=dev, gt=True)
+    # each object cell yields two identical boxes with prob 1; nms thr 1.0 keeps both
+    assert b.shape[0] == 6 and sorted(c.cpu().tolist()) == [3, 3, 7, 7, 11, 11]
+    got = b.cpu().numpy()
+    want = np.concatenate([boxes[:, :2] - boxes[:, 2:] / 2, boxes[:, :2] + boxes[:, 2:] / 2], 1)
+    for w in want:
+        assert np.min(np.abs(got - w).max(1)) < 1e-6

@@ -1,0 +1,76 @@
+"""ctypes binding of libyv1.so -- the C-ABI HIP library (include/yv1.h).
+
+There is no CPU fallback: if the library is missing, ``lib()`` raises.  Device
+pointers are taken from torch tensors (``data_ptr()``), the stream from
+``torch.cuda.current_stream()``; torch is plumbing only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libyv1.so")
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_f = ctypes.c_float
+c_d = ctypes.c_double
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol include/yv1.h declares
+# (tests/test_abi.py checks the two against each other).
+SIGNATURES = {
+    "yv1_loss_workspace_bytes": (c_sz, [c_i, c_i]),
+    "yv1_loss_fwd_bwd": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f,
+                               c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "yv1_scale_by_device_scalar": (c_i, [c_p, c_p, c_ll, c_p]),
+    "yv1_decode_nms_batched": (c_i, [c_p, c_i, c_i, c_i, c_i, c_d, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yv1_nms": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p, c_p]),
+    "yv1_iou_matrix": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
+    "yv1_convert_cxcywh_to_xyxy": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+}
+
+
+class Yv1Error(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libyv1.so once.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Yv1Error(
+                "libyv1.so not found at %s -- build it with `python -m yolo_v1_amd.build` "
+                "(there is no CPU fallback for the HIP hot path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def stream_ptr(device=None):
+    return c_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return c_p(t.data_ptr()) if t is not None else c_p(0)
+
+
+def check(code, what):
+    if code != 0:
+        names = {1001: "bad argument", 1002: "unsupported shape", 1003: "workspace too small"}
+        raise Yv1Error("%s failed: code %d (%s)" % (what, code, names.get(code, "hipError_t")))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise Yv1Error("yolo_v1_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback"
+                           % t.device)

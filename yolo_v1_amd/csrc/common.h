@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels of the YOLO-v1 hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define YV1_OK 0
+#define YV1_ERR_BAD_ARG 1001
+#define YV1_ERR_UNSUPPORTED 1002
+#define YV1_ERR_WORKSPACE 1003
+
+#define YV1_LAUNCH_CHECK()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+#define YV1_HIP(call)                              \
+  do {                                             \
+    hipError_t e__ = (call);                       \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (plain cast path, see MI355X_MICROARCH "Correctness boundaries")
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+// 64-lane wavefront reductions (CDNA wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

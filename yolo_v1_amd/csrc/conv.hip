@@ -1,0 +1,429 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (MI355X / CDNA4): forward and data-gradient.
+//
+// Replaces what the reference gets from cuDNN behind nn.Conv2d: conv3x3/conv1x1
+// (backbones/OriginResNet.py:21-29), the 7x7/2 stem (:121), the projection shortcuts (:159-163),
+// the DenseNet 1x1/3x3 layers (backbones/OriginDenseNet.py:24-29, :52-53) and their dgrad.
+//
+// GEMM view:  D[m][n] = sum_k A[m][k] * B[k][n]
+//   m = GEMM pixel (img, p, q)            M = N*P*Q
+//   n = output channel                    (weights stored [Cout][taps][Cin]: K contiguous)
+//   k = (tap r,s ; input channel c)       K = R*S*Cin, walked tap-major in BK-wide channel blocks
+// A is never materialised: each K-step gathers BM pixel rows x BK channels of ONE tap straight
+// from the NHWC activation (16-B chunks = 8 bf16 channels), zero-filling padded taps.  A generic
+// integer tap map   ih = (p*ah + r*bh + ch) / d  (valid iff divisible and in range)
+// expresses forward (a=stride,b=1,c=-pad,d=1) and dgrad (a=1,b=-1,c=pad,d=stride, weights
+// pre-transposed to [Cin][taps][Cout]) with the same kernel.  The 7x7/2 stem runs as R=7 taps of
+// 32 contiguous elements over a zero-padded NHWC4 image (see yv1_pack_input_nhwc4).
+//
+// Tiling (wave64, v_mfma_f32_32x32x16_bf16): 256 threads = 4 wavefronts per workgroup, each wave
+// owns a (BM/WM)x(BN/WN) sub-tile as 32x32 accumulator blocks; A/B tiles are register-staged
+// (global_load_dwordx4 issued one K-step ahead, ds_write_b128 after the MFMA block) into a
+// double-buffered LDS image whose 16-B chunks are XOR-swizzled so every ds_read_b128 fragment
+// read is bank-conflict-free; one barrier per K-step.
+// Epilogue: per-channel sum / sum-of-squares of the fp32 accumulators (training-mode BatchNorm
+// statistics, nn.BatchNorm2d at OriginResNet.py:123 etc.) reduced in-register + one shuffle and
+// written as per-M-tile partials (deterministic, no atomics); the tile is packed to bf16 through
+// LDS and stored as full 16-B channel runs (optionally accumulating into the destination, used by
+// the strided 1x1 shortcut dgrad).
+// Workgroup -> tile map is XCD-aware: the workgroups that share an XCD (blockIdx % 8) walk the
+// Cout tiles of the same pixel tile back to back, so the gathered A rows are re-read from that
+// XCD's L2, not from HBM.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct ConvArgs {
+  const bf16_t* X;
+  const bf16_t* W;
+  bf16_t* Y;
+  float* stats;        // [MT][2][Cout] partial sums, or nullptr
+  int N, IH, IW, ldx;  // source tensor: pixel stride ldx elements
+  int P, Q;            // GEMM pixel grid per image
+  int Cin, Cout;       // K per tap, GEMM N
+  int R, S;
+  int ah, bh, ch, aw, bw, cw, log2d;
+  int OH, OW, ldy, os; // destination tensor: GEMM pixel (n,p,q) -> (n, p*os, q*os)
+  int accumulate;
+  int M;
+  int MT, NT;
+};
+
+template <int BK>
+__device__ __forceinline__ int swz(int row, int chunk) {
+  constexpr int CPR = BK / 8;                 // 16-B chunks per row
+  return chunk ^ ((row / (16 / CPR)) % CPR);  // conflict-free for the 32x32x16 fragment reads
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
+  constexpr int CPR = BK / 8;
+  constexpr int ROWS_PER_PASS = 256 / CPR;
+  constexpr int A_PASSES = BM / ROWS_PER_PASS;
+  constexpr int B_PASSES = BN / ROWS_PER_PASS;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;   // bytes; pitch/4 % 32 == 16
+  static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for 256 threads");
+  static_assert(2 * STAGE >= BM * EPI_PITCH, "epilogue tile must fit the staging LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+
+  // ---- XCD-aware tile assignment (bijective; blocks b and b+8 share an XCD)
+  int mt, nt;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    mt = lin / a.NT;
+    nt = lin - mt * a.NT;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-thread loader state
+  const int ccol = tid % CPR;          // chunk column inside the K-step
+  const int rrow = tid / CPR;          // first row handled
+  int pix_base[A_PASSES];              // image base (n*IH*IW) or -1 when the row is past M
+  int ph[A_PASSES], qw[A_PASSES];      // p*ah + ch , q*aw + cw
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + rrow + i * ROWS_PER_PASS;
+    if (m < a.M) {
+      const int pq = a.P * a.Q;
+      const int n = m / pq, rem = m - n * pq;
+      const int p = rem / a.Q, q = rem - p * a.Q;
+      pix_base[i] = n * a.IH * a.IW;
+      ph[i] = p * a.ah + a.ch;
+      qw[i] = q * a.aw + a.cw;
+    } else {
+      pix_base[i] = -1; ph[i] = 0; qw[i] = 0;
+    }
+  }
+  const int Ktot = a.R * a.S * a.Cin;
+  const int cblocks = a.Cin / BK;
+  const int nk = a.R * a.S * cblocks;
+  const int dmask = (1 << a.log2d) - 1;
+
+  uint4 ra[A_PASSES], rb[B_PASSES];
+
+  auto load_tiles = [&](int kt) {
+    const int tap = kt / cblocks, cb = kt - tap * cblocks;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int koff = cb * BK + ccol * 8;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int hn = ph[i] + r * a.bh, wn_ = qw[i] + s * a.bw;
+      const int ih = hn >> a.log2d, iw = wn_ >> a.log2d;
+      const bool ok = pix_base[i] >= 0 && ((hn | wn_) & dmask) == 0 && hn >= 0 && wn_ >= 0 && ih < a.IH && iw < a.IW;
+      if (ok) {
+        const size_t off = (size_t)(pix_base[i] + ih * a.IW + iw) * a.ldx + koff;
+        ra[i] = *reinterpret_cast<const uint4*>(a.X + off);
+      } else {
+        ra[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int n = n0 + rrow + i * ROWS_PER_PASS;
+      const size_t off = (size_t)n * Ktot + (size_t)tap * a.Cin + koff;
+      rb[i] = *reinterpret_cast<const uint4*>(a.W + off);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int row = rrow + i * ROWS_PER_PASS;
+      *reinterpret_cast<uint4*>(sa + row * (BK * 2) + swz<BK>(row, ccol) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int row = rrow + i * ROWS_PER_PASS;
+      *reinterpret_cast<uint4*>(sb + row * (BK * 2) + swz<BK>(row, ccol) * 16) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);          // global loads in flight during the MFMA block
+    const unsigned char* sa = smem + cur * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / WM) + i * 32 + l31;
+        fa[i] = *reinterpret_cast<const bf16x8*>(sa + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / WN) + j * 32 + l31;
+        fb[j] = *reinterpret_cast<const bf16x8*>(sb + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue 1: BatchNorm batch statistics from the fp32 accumulators
+  // C/D layout of 32x32: col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel)
+  float* red = reinterpret_cast<float*>(smem + BM * EPI_PITCH);   // [WM][2][BN] floats, after the epilogue tile
+  constexpr bool RED_FITS = (2 * STAGE >= BM * EPI_PITCH + WM * 2 * BN * 4);
+  static_assert(RED_FITS, "no room for the stats scratch");
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][j][e];
+          s += v;
+          ss += v * v;
+        }
+      s += __shfl_xor(s, 32, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lh == 0) {
+        const int c = wn * (BN / WN) + j * 32 + l31;
+        red[(wm * 2 + 0) * BN + c] = s;
+        red[(wm * 2 + 1) * BN + c] = ss;
+      }
+    }
+  }
+
+  // ---- epilogue 2: accumulators -> bf16 tile in LDS (pairs of channels packed via a lane swap)
+  unsigned char* et = smem;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * (BN / WN) + j * 32 + l31;
+      const int rbase = wm * (BM / WM) + i * 32 + 4 * lh;
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const float mine_lo = acc[i][j][e], mine_hi = acc[i][j][e + 1];
+        const bool odd = lane & 1;
+        const float send = odd ? mine_lo : mine_hi;
+        const float recv = __shfl_xor(send, 1, 64);
+        // even lane: row(e), cols (col, col+1) = (mine_lo, partner's acc[e]) ; odd: row(e+1), cols (col-1, col)
+        const int row = rbase + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2);
+        const unsigned v = odd ? pack_bf16x2(recv, mine_hi) : pack_bf16x2(mine_lo, recv);
+        *reinterpret_cast<unsigned*>(et + row * EPI_PITCH + (col & ~1) * 2) = v;
+      }
+    }
+  __syncthreads();
+
+  if (a.stats && tid < BN) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) {
+      s += red[(w * 2 + 0) * BN + tid];
+      ss += red[(w * 2 + 1) * BN + tid];
+    }
+    float* o = a.stats + (size_t)mt * 2 * a.Cout + n0 + tid;
+    o[0] = s;
+    o[a.Cout] = ss;
+  }
+
+  // ---- epilogue 3: full-line stores, 16 B (8 channels) per lane
+  constexpr int OCPR = BN / 8;
+  constexpr int OPASSES = BM * OCPR / 256;
+  static_assert(OPASSES >= 1, "epilogue mapping");
+#pragma unroll
+  for (int i = 0; i < OPASSES; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / OCPR, cc = idx - row * OCPR;
+    const int m = m0 + row;
+    if (m < a.M) {
+      const int pq = a.P * a.Q;
+      const int n = m / pq, rem = m - n * pq;
+      const int p = rem / a.Q, q = rem - p * a.Q;
+      const size_t off = ((size_t)(n * a.OH + p * a.os) * a.OW + q * a.os) * a.ldy + n0 + cc * 8;
+      uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
+      if (a.accumulate) {
+        const uint4 o = *reinterpret_cast<const uint4*>(a.Y + off);
+        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+        const unsigned* po = reinterpret_cast<const unsigned*>(&o);
+        unsigned res[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = __uint_as_float(pv[k] << 16) + __uint_as_float(po[k] << 16);
+          const float hi = __uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(po[k] & 0xffff0000u);
+          res[k] = pack_bf16x2(lo, hi);
+        }
+        v = make_uint4(res[0], res[1], res[2], res[3]);
+      }
+      *reinterpret_cast<uint4*>(a.Y + off) = v;
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch(ConvArgs& a, hipStream_t stream) {
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  a.MT = (a.M + BM - 1) / BM;
+  a.NT = a.Cout / BN;
+  const size_t lds = 2 * STAGE;
+  auto kern = k_conv_gemm<BM, BN, BK, WM, WN>;
+  if (lds > 64 * 1024) {
+    static bool once = false;
+    if (!once) {
+      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      once = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(256), lds, stream, a);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+int dispatch(ConvArgs& a, hipStream_t stream) {
+  if (a.Cin % 32 || a.Cout % 32 || a.ldx % 8 || a.ldy % 8) return YV1_ERR_UNSUPPORTED;
+  const bool k64 = (a.Cin % 64) == 0;
+  const long long tiles128 = (long long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+  if (a.Cout % 128 == 0 && tiles128 >= 512) {
+    return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
+  }
+  if (a.Cout % 64 == 0) {
+    const long long tiles = (long long)((a.M + 127) / 128) * (a.Cout / 64);
+    if (tiles >= 512) return k64 ? launch<128, 64, 64, 2, 2>(a, stream) : launch<128, 64, 32, 2, 2>(a, stream);
+    return k64 ? launch<64, 64, 64, 2, 2>(a, stream) : launch<64, 64, 32, 2, 2>(a, stream);
+  }
+  return k64 ? launch<128, 32, 64, 4, 1>(a, stream) : launch<128, 32, 32, 4, 1>(a, stream);
+}
+
+// NCHW fp32 image -> zero-padded NHWC4 bf16 [N][H+6][W+6][4] (pad 3 each side, channel 3 = 0).
+__global__ void k_pack_input(const float* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W) {
+  const int HP = H + 6, WP = W + 6;
+  const long long total = (long long)N * HP * WP;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int wp = (int)(i % WP);
+    const long long t = i / WP;
+    const int hp = (int)(t % HP), n = (int)(t / HP);
+    const int h = hp - 3, w = wp - 3;
+    uint2 o = make_uint2(0, 0);
+    if (h >= 0 && h < H && w >= 0 && w < W) {
+      const size_t plane = (size_t)H * W;
+      const float* src = x + (size_t)n * 3 * plane + (size_t)h * W + w;
+      o.x = pack_bf16x2(src[0], src[plane]);
+      o.y = pack_bf16x2(src[2 * plane], 0.f);
+    }
+    *reinterpret_cast<uint2*>(y + i * 4) = o;
+  }
+}
+
+}  // namespace
+
+// Forward convolution, NHWC bf16, square kernel k, stride, pad; optional BN-statistic partials.
+// x: [N,IH,IW,*] with pixel stride ldx; w: [Cout][k*k][Cin] bf16; y: [N,OH,OW,*] with pixel stride ldy.
+// stats (nullable): [ceil(M/BM)][2][Cout] fp32 partial sums where the number of partial rows is
+// returned by yv1_conv2d_stats_rows().
+extern "C" int yv1_conv2d_fwd_nhwc_bf16(const void* x, const void* w, void* y, int N, int IH, int IW, int ldx, int Cin,
+                                        int Cout, int ldy, int k, int stride, int pad, float* stats,
+                                        hipStream_t stream) {
+  if (!x || !w || !y || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
+  ConvArgs a;
+  a.X = (const bf16_t*)x; a.W = (const bf16_t*)w; a.Y = (bf16_t*)y; a.stats = stats;
+  a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx;
+  a.P = (IH + 2 * pad - k) / stride + 1; a.Q = (IW + 2 * pad - k) / stride + 1;
+  a.Cin = Cin; a.Cout = Cout; a.R = k; a.S = k;
+  a.ah = stride; a.bh = 1; a.ch = -pad; a.aw = stride; a.bw = 1; a.cw = -pad; a.log2d = 0;
+  a.OH = a.P; a.OW = a.Q; a.ldy = ldy; a.os = 1; a.accumulate = 0;
+  a.M = N * a.P * a.Q;
+  return dispatch(a, stream);
+}
+
+// Stem: 7x7 stride-2 pad-3 convolution of the packed NHWC4 image (yv1_pack_input_nhwc4).
+// xp: [N][H+6][W+6][4] bf16; w: [Cout][7][32] bf16 (element s*4+c of row r; zero for c==3 and s==7).
+extern "C" int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy,
+                                        float* stats, hipStream_t stream) {
+  if (!xp || !w || !y || N <= 0 || (H & 1) || (W & 1)) return YV1_ERR_BAD_ARG;
+  ConvArgs a;
+  a.X = (const bf16_t*)xp; a.W = (const bf16_t*)w; a.Y = (bf16_t*)y; a.stats = stats;
+  a.N = N; a.IH = H + 6; a.IW = W + 6; a.ldx = 4;       // "pixel" = 4 elements; one tap row = 32 contiguous elements
+  a.P = H / 2; a.Q = W / 2;
+  a.Cin = 32; a.Cout = Cout; a.R = 7; a.S = 1;
+  a.ah = 2; a.bh = 1; a.ch = 0; a.aw = 2; a.bw = 0; a.cw = 0; a.log2d = 0;
+  a.OH = a.P; a.OW = a.Q; a.ldy = ldy; a.os = 1; a.accumulate = 0;
+  a.M = N * a.P * a.Q;
+  a.ldx = 4;
+  if (Cout % 64) return YV1_ERR_UNSUPPORTED;
+  // the last tap row of the last pixel reads up to element ((IH-1)*IW + 2*(Q-1))*4 + 31 < IH*IW*4
+  return launch<128, 64, 32, 2, 2>(a, stream);
+}
+
+// Data gradient.  dy: [N,OH,OW,*] (pixel stride lddy, Cout channels); wt: [Cin][k*k][Cout] bf16 (the
+// transposed copy); dx: [N,IH,IW,*] (pixel stride lddx, Cin channels).  accumulate != 0 adds into dx.
+// 1x1 strided convolutions touch only the pixels (h*stride, w*stride) -- with accumulate == 0 the other
+// pixels of dx are NOT written (the caller zero-fills or, as the residual shortcut does, accumulates
+// into a dx that the main path has already written).
+extern "C" int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx,
+                                          int Cin, int Cout, int lddy, int k, int stride, int pad, int accumulate,
+                                          hipStream_t stream) {
+  if (!dy || !wt || !dx || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
+  if (stride != 1 && stride != 2) return YV1_ERR_UNSUPPORTED;
+  const int OH = (IH + 2 * pad - k) / stride + 1, OW = (IW + 2 * pad - k) / stride + 1;
+  ConvArgs a;
+  a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx; a.stats = nullptr;
+  a.N = N; a.IH = OH; a.IW = OW; a.ldx = lddy;
+  a.Cin = Cout; a.Cout = Cin; a.R = k; a.S = k;
+  a.OH = IH; a.OW = IW; a.ldy = lddx; a.accumulate = accumulate;
+  if (k == 1 && pad == 0) {
+    // GEMM over the dy pixels, scattered to (h*stride, w*stride)
+    a.P = OH; a.Q = OW; a.os = stride;
+    a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
+  } else {
+    // GEMM over the dx pixels; tap (r,s) reads dy at ((h + pad - r)/stride, (w + pad - s)/stride)
+    a.P = IH; a.Q = IW; a.os = 1;
+    a.ah = 1; a.bh = -1; a.ch = pad; a.aw = 1; a.bw = -1; a.cw = pad; a.log2d = (stride == 2) ? 1 : 0;
+  }
+  a.M = N * a.P * a.Q;
+  return dispatch(a, stream);
+}
+
+extern "C" int yv1_conv2d_stats_rows(int M, int Cout, int Cin) {
+  // number of partial rows the forward kernel writes for this shape (mirrors dispatch())
+  const long long tiles128 = (long long)((M + 127) / 128) * ((Cout + 127) / 128);
+  if (Cout % 128 == 0 && tiles128 >= 512) return (M + 127) / 128;
+  if (Cout % 64 == 0) {
+    const long long tiles = (long long)((M + 127) / 128) * (Cout / 64);
+    return tiles >= 512 ? (M + 127) / 128 : (M + 63) / 64;
+  }
+  return (M + 127) / 128;
+}
+
+extern "C" int yv1_pack_input_nhwc4(const float* x_nchw, void* y, int N, int H, int W, hipStream_t stream) {
+  if (!x_nchw || !y || N <= 0) return YV1_ERR_BAD_ARG;
+  const long long total = (long long)N * (H + 6) * (W + 6);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_pack_input, dim3(blocks), dim3(256), 0, stream, x_nchw, (bf16_t*)y, N, H, W);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
