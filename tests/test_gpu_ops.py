@@ -1,0 +1,237 @@
+"""GPU parity of the individual HIP kernels (through the C-ABI) against torch-CPU fp32 references
+computed on the same bf16-rounded inputs.
+
+Tolerances (stated per SURVEY 8d): bf16-in / fp32-accumulate kernels vs fp32 on identical
+bf16-rounded inputs differ only by the final bf16 rounding of the output (rel 2^-8 = 3.9e-3) plus
+fp32 summation order, so outputs are compared with rtol 1e-2 / atol 1e-2*scale; fp32 outputs
+(weight gradients, statistics) with rtol 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def nhwc_act(x_nchw):
+    """fp32 NCHW cpu -> Act (bf16 NHWC on device)."""
+    from yolo_v1_amd import ops
+    return ops.Act(x_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV))
+
+
+def to_nchw(act, C=None):
+    t = act.t.float().cpu()
+    if C is not None:
+        t = t[..., :C]
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+class W:
+    """minimal stand-in for a ConvParam"""
+
+    def __init__(self, w, k, stride, pad, stem=False):
+        from yolo_v1_amd import ops
+        self.param = torch.nn.Parameter(w.to(DEV).contiguous(memory_format=torch.channels_last))
+        self.cw = ops.ConvWeights(self.param, k, stride, pad, stem=stem)
+        self.cw.refresh()
+
+
+def close(got, want, rtol=1e-2, scale_atol=1e-2):
+    want = want.float()
+    atol = scale_atol * float(want.abs().max() + 1e-6)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=rtol, atol=atol)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 1, 1, 0),
+    (2, 16, 16, 64, 256, 1, 1, 0),
+    (3, 14, 14, 256, 64, 1, 1, 0),
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (2, 16, 16, 128, 128, 3, 2, 1),
+    (2, 14, 14, 256, 512, 1, 2, 0),
+    (1, 7, 7, 512, 512, 3, 1, 1),
+    (2, 7, 9, 96, 128, 1, 1, 0),        # DenseNet: Cin multiple of 32 only
+    (2, 12, 12, 128, 32, 3, 1, 1),      # DenseNet growth conv
+    (2, 7, 7, 2048, 30, 1, 1, 0),       # head (Cout padded to 32)
+    (9, 28, 28, 128, 128, 3, 1, 1),     # enough tiles for the 128x128 kernel
+    (8, 56, 56, 64, 256, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,k,stride,pad", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(N, H, Wd, Cin, Cout, k, stride, pad):
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin + Cout + k)
+    x = bf(torch.randn(N, Cin, H, Wd, generator=g))
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+    ref = F.conv2d(x, w, stride=stride, padding=pad)
+    OH, OW = ref.shape[2:]
+    wm = W(w, k, stride, pad)
+    xa = nhwc_act(x)
+    ya = ops.new_act(N, OH, OW, wm.cw.Opad, DEV)
+    stats = ops.conv_fwd(xa, wm.cw, ya, True)
+    torch.cuda.synchronize()
+    close(to_nchw(ya, Cout), ref)
+    # BN statistic partials from the epilogue: sum and sum of squares per channel
+    s = stats.sum(0).cpu()
+    np.testing.assert_allclose(s[0, :Cout].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=2e-2 * float(ref.abs().max()))
+    np.testing.assert_allclose(s[1, :Cout].numpy(), (ref * ref).sum((0, 2, 3)).numpy(), rtol=2e-3, atol=1e-2)
+    # gradients
+    gy = bf(torch.randn(ref.shape, generator=g))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, stride=stride, padding=pad).backward(gy)
+    gy_pad = torch.zeros(N, wm.cw.Opad, OH, OW)
+    gy_pad[:, :Cout] = gy
+    dya = nhwc_act(gy_pad)
+    dxa = ops.new_act(N, H, Wd, Cin, DEV)
+    if k == 1 and stride == 2:
+        dxa.t.zero_()                      # strided 1x1 dgrad only touches the sampled pixels
+    ops.conv_dgrad(dya, wm.cw, dxa)
+    gw = ops.conv_wgrad(xa, dya, wm.cw)
+    torch.cuda.synchronize()
+    close(to_nchw(dxa), xr.grad)
+    assert tuple(gw.shape) == (Cout, Cin, k, k)
+    np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=2e-3, atol=2e-3 * float(wr.grad.abs().max()))
+    # accumulate mode
+    base = bf(torch.randn(N, Cin, H, Wd, generator=g))
+    dxb = nhwc_act(base)
+    ops.conv_dgrad(dya, wm.cw, dxb, accumulate=True)
+    torch.cuda.synchronize()
+    close(to_nchw(dxb), bf(xr.grad) + base, rtol=2e-2, scale_atol=2e-2)
+
+
+def test_stem_fwd_wgrad():
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, Wd = 2, 64, 128
+    x = torch.randn(N, 3, H, Wd, generator=g)
+    w = bf(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    xb = bf(x)
+    ref = F.conv2d(xb, w, stride=2, padding=3)
+    wm = W(w, 7, 2, 3, stem=True)
+    xp = ops.pack_input(x.to(DEV))
+    ya = ops.new_act(N, H // 2, Wd // 2, 64, DEV)
+    stats = ops.stem_fwd(xp, wm.cw, ya, H, Wd)
+    torch.cuda.synchronize()
+    close(to_nchw(ya), ref)
+    np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=0.05)
+    gy = bf(torch.randn(ref.shape, generator=g))
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xb, wr, stride=2, padding=3).backward(gy)
+    gw = ops.stem_wgrad(xp, nhwc_act(gy), wm.cw, H, Wd)
+    torch.cuda.synchronize()
+    assert tuple(gw.shape) == (64, 3, 7, 7)
+    np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=2e-3, atol=2e-3 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("C,N,H", [(64, 4, 12), (96, 2, 7), (256, 3, 9), (992, 2, 5), (2048, 2, 3)])
+def test_bn_forward_backward(C, N, H):
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(C)
+    y = bf(torch.randn(N, C, H, H, generator=g) * 2 + 0.5)
+    res = bf(torch.randn(N, C, H, H, generator=g))
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data.uniform_(0.5, 1.5, generator=g)
+    bn.bias.data.uniform_(-0.5, 0.5, generator=g)
+    ref_bn = torch.nn.BatchNorm2d(C)
+    ref_bn.load_state_dict(bn.state_dict())
+    bn = bn.to(DEV)
+    ya, ra = nhwc_act(y), nhwc_act(res)
+    st = ops.bn_finalize(ops.bn_stats(ya), ya.npix, bn)
+    za = ops.new_act(N, H, H, C, DEV)
+    ops.bn_apply(ya, st, za, relu=True, residual=ra)
+    yr = y.clone().requires_grad_(True)
+    zr = F.relu(ref_bn(yr) + res)
+    torch.cuda.synchronize()
+    close(to_nchw(za), zr.detach())
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref_bn.running_mean.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref_bn.running_var.numpy(), rtol=1e-4, atol=1e-5)
+    # backward with the ReLU mask taken from z (mode 1) + shortcut gradient copy
+    gz = bf(torch.randn(N, C, H, H, generator=g))
+    zr.backward(gz)
+    dya, dra = ops.new_act(N, H, H, C, DEV), ops.new_act(N, H, H, C, DEV)
+    dg, db = ops.bn_backward(nhwc_act(gz), ya, st, bn, dya, 1, z=za, dres=dra)
+    torch.cuda.synchronize()
+    close(to_nchw(dya), yr.grad, rtol=2e-2, scale_atol=2e-2)
+    np.testing.assert_allclose(dg.cpu().numpy(), ref_bn.weight.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.weight.grad.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.bias.grad.abs().max()))
+    mask = (zr.detach() > 0).float()
+    close(to_nchw(dra), gz * mask, rtol=1e-2, scale_atol=1e-2)
+    # mode 2 (mask from scale*y+shift) without residual, accumulate into an existing gradient
+    yr2 = y.clone().requires_grad_(True)
+    ref_bn.zero_grad()
+    F.relu(ref_bn(yr2)).backward(gz)
+    base = bf(torch.randn(N, C, H, H, generator=g))
+    dyb = nhwc_act(base)
+    ops.bn_backward(nhwc_act(gz), ya, st, bn, dyb, 2, accumulate=True)
+    torch.cuda.synchronize()
+    close(to_nchw(dyb), yr2.grad + base, rtol=2e-2, scale_atol=2e-2)
+
+
+def test_pools():
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = bf(F.relu(torch.randn(2, 64, 14, 18, generator=g)))     # post-ReLU: many exact ties at 0
+    xa = nhwc_act(x)
+    ya = ops.new_act(2, 7, 9, 64, DEV)
+    ops.maxpool_fwd(xa, ya)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(to_nchw(ya).numpy(), yr.detach().numpy())
+    gy = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    dxa = ops.new_act(2, 14, 18, 64, DEV)
+    ops.maxpool_bwd(xa, nhwc_act(gy), dxa)
+    torch.cuda.synchronize()
+    close(to_nchw(dxa), xr.grad, rtol=1e-2, scale_atol=1e-2)
+    # average pool
+    x2 = bf(torch.randn(2, 128, 8, 6, generator=g))
+    x2a = nhwc_act(x2)
+    y2a = ops.new_act(2, 4, 3, 128, DEV)
+    ops.avgpool_fwd(x2a, y2a)
+    torch.cuda.synchronize()
+    close(to_nchw(y2a), F.avg_pool2d(x2, 2, 2))
+    gy2 = bf(torch.randn(2, 128, 4, 3, generator=g))
+    dx2 = ops.new_act(2, 8, 6, 128, DEV)
+    ops.avgpool_bwd(nhwc_act(gy2), dx2)
+    torch.cuda.synchronize()
+    close(to_nchw(dx2), F.interpolate(gy2, scale_factor=2, mode="nearest") * 0.25)
+
+
+def test_head_fwd_bwd():
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(8)
+    N, S, C = 4, 7, 30
+    y = torch.zeros(N, 32, S, S)
+    y[:, :C] = bf(torch.randn(N, C, S, S, generator=g))
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data.uniform_(0.5, 1.5, generator=g)
+    ref_bn = torch.nn.BatchNorm2d(C)
+    ref_bn.load_state_dict(bn.state_dict())
+    bn = bn.to(DEV)
+    ya = nhwc_act(y)
+    st = ops.bn_finalize(ops.bn_stats(ya), ya.npix, bn, C)
+    out = ops.head_fwd(ya, st, C)
+    yr = y[:, :C].clone().requires_grad_(True)
+    ref = torch.sigmoid(ref_bn(yr)).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    go = torch.randn(N, S, S, C, generator=g)
+    ref.backward(go)
+    dya = ops.new_act(N, S, S, 32, DEV)
+    dg, db = ops.head_bwd(go.to(DEV), out, ya, st, bn, dya)
+    torch.cuda.synchronize()
+    got = to_nchw(dya)
+    close(got[:, :C], yr.grad, rtol=1e-2, scale_atol=1e-2)
+    assert not got[:, C:].any()
+    np.testing.assert_allclose(dg.cpu().numpy(), ref_bn.weight.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=1e-3, atol=1e-4)

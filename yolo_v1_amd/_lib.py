@@ -31,6 +31,38 @@ SIGNATURES = {
     "yv1_nms": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p, c_p]),
     "yv1_iou_matrix": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
     "yv1_convert_cxcywh_to_xyxy": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    # conv.hip
+    "yv1_conv2d_fwd_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "yv1_conv2d_stem_fwd_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "yv1_conv2d_dgrad_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_conv2d_stats_rows": (c_i, [c_i, c_i, c_i]),
+    "yv1_pack_input_nhwc4": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    # wgrad.hip
+    "yv1_conv2d_wgrad_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "yv1_conv2d_wgrad_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "yv1_conv2d_stem_wgrad_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "yv1_conv2d_stem_wgrad_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    # elementwise.hip
+    "yv1_reduce_rows": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "yv1_bn_finalize": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yv1_bn_eval_coeffs": (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
+    "yv1_bn_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p]),
+    "yv1_bn_reduce_rows": (c_i, [c_ll, c_i]),
+    "yv1_bn_stats": (c_i, [c_p, c_i, c_ll, c_i, c_p, c_p]),
+    "yv1_bn_bwd_reduce": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p]),
+    "yv1_bn_bwd_finalize": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yv1_bn_bwd_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i,
+                               c_p, c_i, c_p, c_i, c_i, c_p]),
+    "yv1_stats_merge": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "yv1_maxpool3x3s2_fwd": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_maxpool3x3s2_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_avgpool2_fwd": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_avgpool2_bwd": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_head_sigmoid_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_ll, c_i, c_p]),
+    "yv1_head_sigmoid_bwd": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_ll, c_i, c_p]),
+    "yv1_prep_weights": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "yv1_prep_stem_weights": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p, c_p]),
+    "yv1_unpack_stem_grad": (c_i, [c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p]),
 }
 
 

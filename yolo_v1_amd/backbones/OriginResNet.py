@@ -1,0 +1,208 @@
+"""Drop-in for the reference's ``backbones/OriginResNet.py`` on MI355X.
+
+``resnet50(pretrained=False, S=7)`` returns an ``nn.Module`` with the reference's state_dict keys
+and OIHW weight shapes (conv1, bn1, layer{1..5}.{i}.conv{1,2,3} / bn{1,2,3} / downsample.{0,1},
+layer6, bn_end -- OriginResNet.py:112-134,:155-171) whose forward maps fp32 NCHW images to
+``[N, S, S, B*5+C]`` sigmoid outputs (:173-195).  Nothing of it runs through ATen: the module
+tree only holds parameters; forward and backward are explicit HIP launch sequences over NHWC
+bf16 activations (csrc/conv.hip, wgrad.hip, elementwise.hip), recorded as one autograd node.
+
+Per Bottleneck (OriginResNet.py:87-107), forward:
+    y1 = conv1x1(x)            + BN statistics in the conv epilogue
+    z1 = relu(bn1(y1))
+    y2 = conv3x3(z1, stride)   (stride on the 3x3, :79)
+    z2 = relu(bn2(y2))
+    y3 = conv1x1(z2)
+    yd = conv1x1(x, stride)    projection shortcut when the shape changes (:159-163)
+    out = relu(bn3(y3) + (bn_d(yd) | x))      one fused elementwise kernel
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from ..engine import ConvParam, HipBackbone, make_bn
+
+__all__ = ['ResNet', 'resnet50']
+
+EXPANSION = 4
+
+
+class Bottleneck(nn.Module):
+    """Parameter container for one bottleneck (keys conv1,bn1,conv2,bn2,conv3,bn3[,downsample.0/.1])."""
+
+    def __init__(self, inplanes, planes, stride=1, project=False):
+        super().__init__()
+        self.conv1 = ConvParam(inplanes, planes, 1)
+        self.bn1 = make_bn(planes)
+        self.conv2 = ConvParam(planes, planes, 3, stride, 1)
+        self.bn2 = make_bn(planes)
+        self.conv3 = ConvParam(planes, planes * EXPANSION, 1)
+        self.bn3 = make_bn(planes * EXPANSION)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(ConvParam(inplanes, planes * EXPANSION, 1, stride), make_bn(planes * EXPANSION))
+        self.stride = stride
+
+
+class ResNet(HipBackbone):
+    # (state_dict name, planes, stride); block counts come from ``layers``
+    STAGES = (("layer1", 64, 1), ("layer2", 128, 2), ("layer3", 256, 2), ("layer4", 512, 2))
+
+    def __init__(self, layers=(3, 4, 6, 3), S=7, B=2, num_classes=20):
+        super().__init__()
+        self.S7 = S == 7
+        self.out_channels = B * 5 + num_classes
+        self.conv1 = ConvParam(3, 64, 7, 2, 3)
+        self.bn1 = make_bn(64)
+        inpl = 64
+        stages = [(n, p, s, layers[i]) for i, (n, p, s) in enumerate(self.STAGES)]
+        if self.S7:
+            stages.append(("layer5", 512, 2, layers[3]))     # extra stride-2 stage for the 7x7 grid (:131-132)
+        self._stage_names = [s[0] for s in stages]
+        for name, planes, stride, nblocks in stages:
+            blocks = []
+            for i in range(nblocks):
+                st = stride if i == 0 else 1
+                blocks.append(Bottleneck(inpl, planes, st, project=(i == 0 and (st != 1 or inpl != planes * EXPANSION))))
+                inpl = planes * EXPANSION
+            setattr(self, name, nn.Sequential(*blocks))
+        self.layer6 = ConvParam(inpl, self.out_channels, 1)      # head, :133
+        self.bn_end = make_bn(self.out_channels)
+        for m in self.modules():                                  # init as :138-143
+            if isinstance(m, ConvParam):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    # ------------------------------------------------------------------ forward executor
+    def _blocks(self):
+        for name in self._stage_names:
+            for blk in getattr(self, name):
+                yield blk
+
+    def _run_forward(self, images, train, save):
+        dev = images.device
+        N, _, H, W = images.shape
+        if H % 64 or W % 64:
+            raise _lib.Yv1Error("input height/width must be multiples of 64, got %dx%d" % (H, W))
+        bns = []
+
+        def norm(stats, count, bn, C=None):
+            if train:
+                bns.append(bn)
+                return ops.bn_finalize(stats, count, bn, C)
+            return ops.bn_eval_state(bn)
+
+        rec = {"blocks": []}
+        # stem: 7x7/2 conv -> BN -> ReLU -> maxpool 3x3/2                       (:174-177)
+        w0 = self.cw(self.conv1, stem=True)
+        xp = ops.pack_input(images)
+        y0 = ops.new_act(N, H // 2, W // 2, 64, dev)
+        s0 = norm(ops.stem_fwd(xp, w0, y0, H, W), y0.npix, self.bn1)
+        z0 = ops.new_act(N, H // 2, W // 2, 64, dev)
+        ops.bn_apply(y0, s0, z0, relu=True)
+        x = ops.new_act(N, H // 4, W // 4, 64, dev)
+        ops.maxpool_fwd(z0, x)
+        rec["stem"] = (xp, y0, s0, z0, H, W)
+
+        for blk in self._blocks():
+            w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
+            planes = blk.conv1.out_channels
+            y1 = ops.new_act(N, x.H, x.W, planes, dev)
+            s1 = norm(ops.conv_fwd(x, w1, y1, train), y1.npix, blk.bn1)
+            z1 = ops.new_act(N, x.H, x.W, planes, dev)
+            ops.bn_apply(y1, s1, z1, relu=True)
+            h2, w2_ = ops.conv_out_hw(x.H, x.W, 3, blk.stride, 1)
+            y2 = ops.new_act(N, h2, w2_, planes, dev)
+            s2 = norm(ops.conv_fwd(z1, w2, y2, train), y2.npix, blk.bn2)
+            z2 = ops.new_act(N, h2, w2_, planes, dev)
+            ops.bn_apply(y2, s2, z2, relu=True)
+            y3 = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
+            s3 = norm(ops.conv_fwd(z2, w3, y3, train), y3.npix, blk.bn3)
+            out = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
+            yd = sd = None
+            if blk.downsample is not None:
+                wd = self.cw(blk.downsample[0])
+                yd = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
+                sd = norm(ops.conv_fwd(x, wd, yd, train), yd.npix, blk.downsample[1])
+                ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd)
+            else:
+                ops.bn_apply(y3, s3, out, relu=True, residual=x)
+            if save:
+                rec["blocks"].append((blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out))
+            x = out
+
+        # head: 1x1 conv -> bn_end -> sigmoid, already NHWC                      (:186-189)
+        wh = self.cw(self.layer6)
+        yh = ops.new_act(N, x.H, x.W, wh.Opad, dev)
+        sh = norm(ops.conv_fwd(x, wh, yh, train), yh.npix, self.bn_end, self.out_channels)
+        pred = ops.head_fwd(yh, sh, self.out_channels)
+        rec["head"] = (x, yh, sh, pred)
+        if train:
+            self._bump_counters(bns)
+        return pred, (rec if save else None)
+
+    # ------------------------------------------------------------------ backward executor
+    def _run_backward(self, rec, gpred):
+        grads = {}
+        x, yh, sh, pred = rec["head"]
+        dev = pred.device
+        N = yh.N
+        wh = self.cw(self.layer6)
+        dyh = ops.new_act(N, yh.H, yh.W, wh.Opad, dev)
+        dg, db = ops.head_bwd(gpred, pred, yh, sh, self.bn_end, dyh)
+        grads[self.bn_end.weight], grads[self.bn_end.bias] = dg, db
+        grads[self.layer6.weight] = ops.conv_wgrad(x, dyh, wh)
+        g = ops.new_act(N, x.H, x.W, x.C, dev)
+        ops.conv_dgrad(dyh, wh, g)
+
+        for (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out) in reversed(rec["blocks"]):
+            w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
+            g_in = ops.new_act(N, x.H, x.W, x.C, dev)
+            dy3 = ops.new_act(N, y3.H, y3.W, y3.C, dev)
+            if yd is not None:
+                wd = self.cw(blk.downsample[0])
+                bnd = blk.downsample[1]
+                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 1, z=out)
+                dyd = ops.new_act(N, yd.H, yd.W, yd.C, dev)
+                grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 1, z=out)
+                grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd)
+            else:
+                # identity shortcut: the masked gradient is also the shortcut's contribution to g_in
+                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 1, z=out, dres=g_in)
+            grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3)
+            dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
+            ops.conv_dgrad(dy3, w3, dz2)
+            dy2 = ops.new_act(N, y2.H, y2.W, y2.C, dev)
+            grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
+            grads[blk.conv2.weight] = ops.conv_wgrad(z1, dy2, w2)
+            dz1 = ops.new_act(N, z1.H, z1.W, z1.C, dev)
+            ops.conv_dgrad(dy2, w2, dz1)
+            dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
+            grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
+            grads[blk.conv1.weight] = ops.conv_wgrad(x, dy1, w1)
+            if yd is not None:
+                ops.conv_dgrad(dy1, w1, g_in, accumulate=False)
+                ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate
+            else:
+                ops.conv_dgrad(dy1, w1, g_in, accumulate=True)
+            g = g_in
+
+        xp, y0, s0, z0, H, W = rec["stem"]
+        w0 = self.cw(self.conv1, stem=True)
+        dz0 = ops.new_act(N, z0.H, z0.W, 64, dev)
+        ops.maxpool_bwd(z0, g, dz0)
+        dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
+        grads[self.bn1.weight], grads[self.bn1.bias] = ops.bn_backward(dz0, y0, s0, self.bn1, dy0, 2)
+        grads[self.conv1.weight] = ops.stem_wgrad(xp, dy0, w0, H, W)
+        return grads
+
+
+def resnet50(pretrained=False, S=7, **kwargs):
+    """ResNet-50 backbone + YOLO head (OriginResNet.py:220-231).  ``pretrained`` needs a network
+    fetch in the reference (:229-230) and is not available offline: load weights by name with
+    ``load_state_dict`` instead (train.py:61-67)."""
+    if S not in [7, 14]:
+        print('S musk be 7x7 or 14x14')      # same idiom as the reference (:225-227)
+        exit()
+    if pretrained:
+        raise _lib.Yv1Error("pretrained=True would download from download.pytorch.org; load a state_dict instead")
+    return ResNet((3, 4, 6, 3), S=S, **kwargs)

@@ -34,6 +34,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct ConvArgs {
   const bf16_t* X;
@@ -61,14 +62,13 @@ template <int BM, int BN, int BK, int WM, int WN>
 __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
   constexpr int CPR = BK / 8;
   constexpr int ROWS_PER_PASS = 256 / CPR;
-  constexpr int A_PASSES = BM / ROWS_PER_PASS;
-  constexpr int B_PASSES = BN / ROWS_PER_PASS;
+  constexpr int A_PASSES = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+  constexpr int B_PASSES = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+  constexpr bool A_GUARD = (BM % ROWS_PER_PASS) != 0, B_GUARD = (BN % ROWS_PER_PASS) != 0;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;   // bytes; pitch/4 % 32 == 16
-  static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for 256 threads");
-  static_assert(2 * STAGE >= BM * EPI_PITCH, "epilogue tile must fit the staging LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -109,45 +109,45 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
   const int nk = a.R * a.S * cblocks;
   const int dmask = (1 << a.log2d) - 1;
 
-  uint4 ra[A_PASSES], rb[B_PASSES];
+  u32x4 ra[A_PASSES], rb[B_PASSES];
 
-  auto load_tiles = [&](int kt) {
-    const int tap = kt / cblocks, cb = kt - tap * cblocks;
-    const int r = tap / a.S, s = tap - r * a.S;
-    const int koff = cb * BK + ccol * 8;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int hn = ph[i] + r * a.bh, wn_ = qw[i] + s * a.bw;
-      const int ih = hn >> a.log2d, iw = wn_ >> a.log2d;
-      const bool ok = pix_base[i] >= 0 && ((hn | wn_) & dmask) == 0 && hn >= 0 && wn_ >= 0 && ih < a.IH && iw < a.IW;
-      if (ok) {
-        const size_t off = (size_t)(pix_base[i] + ih * a.IW + iw) * a.ldx + koff;
-        ra[i] = *reinterpret_cast<const uint4*>(a.X + off);
-      } else {
-        ra[i] = make_uint4(0, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const int n = n0 + rrow + i * ROWS_PER_PASS;
-      const size_t off = (size_t)n * Ktot + (size_t)tap * a.Cin + koff;
-      rb[i] = *reinterpret_cast<const uint4*>(a.W + off);
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    unsigned char* sa = smem + buf * STAGE;
-    unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int row = rrow + i * ROWS_PER_PASS;
-      *reinterpret_cast<uint4*>(sa + row * (BK * 2) + swz<BK>(row, ccol) * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const int row = rrow + i * ROWS_PER_PASS;
-      *reinterpret_cast<uint4*>(sb + row * (BK * 2) + swz<BK>(row, ccol) * 16) = rb[i];
-    }
-  };
+#define YV1_LOAD_TILES(KT_)                                                                                      \
+  {                                                                                                              \
+    const int kt__ = (KT_);                                                                                      \
+    const int tap = kt__ / cblocks, cb = kt__ - tap * cblocks;                                                   \
+    const int r = tap / a.S, s = tap - r * a.S;                                                                  \
+    const int koff = cb * BK + ccol * 8;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const int hn = ph[i] + r * a.bh, wn_ = qw[i] + s * a.bw;                                                   \
+      const int ih = hn >> a.log2d, iw = wn_ >> a.log2d;                                                         \
+      const bool ok = (!A_GUARD || rrow + i * ROWS_PER_PASS < BM) && pix_base[i] >= 0 &&                         \
+                      ((hn | wn_) & dmask) == 0 && hn >= 0 && wn_ >= 0 && ih < a.IH && iw < a.IW;                \
+      const size_t off = ok ? (size_t)(pix_base[i] + ih * a.IW + iw) * a.ldx + koff : 0;                         \
+      u32x4 v = {0u, 0u, 0u, 0u};                                                                                \
+      if (ok) v = *reinterpret_cast<const u32x4*>(a.X + off);                                                    \
+      ra[i] = v;                                                                                                 \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
+      const int n = n0 + rrow + i * ROWS_PER_PASS;                                                               \
+      const bool ok = !B_GUARD || rrow + i * ROWS_PER_PASS < BN;                                                 \
+      u32x4 v = {0u, 0u, 0u, 0u};                                                                                \
+      if (ok) v = *reinterpret_cast<const u32x4*>(a.W + (size_t)n * Ktot + (size_t)tap * a.Cin + koff);         \
+      rb[i] = v;                                                                                                 \
+    }                                                                                                            \
+  }
+#define YV1_STORE_TILES(BUF_)                                                                                    \
+  {                                                                                                              \
+    unsigned char* sa_ = smem + (BUF_) * STAGE;                                                                  \
+    unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const int row = rrow + i * ROWS_PER_PASS;                                                                  \
+      if (!A_GUARD || row < BM) *reinterpret_cast<u32x4*>(sa_ + row * (BK * 2) + swz<BK>(row, ccol) * 16) = ra[i]; \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
+      const int row = rrow + i * ROWS_PER_PASS;                                                                  \
+      if (!B_GUARD || row < BN) *reinterpret_cast<u32x4*>(sb_ + row * (BK * 2) + swz<BK>(row, ccol) * 16) = rb[i]; \
+    }                                                                                                            \
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -157,14 +157,14 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tiles(0);
-  store_tiles(0);
+  YV1_LOAD_TILES(0);
+  YV1_STORE_TILES(0);
   __syncthreads();
 
   const int l31 = lane & 31, lh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);          // global loads in flight during the MFMA block
+    if (kt + 1 < nk) YV1_LOAD_TILES(kt + 1);      // global loads in flight during the MFMA block
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
@@ -186,15 +186,13 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    if (kt + 1 < nk) YV1_STORE_TILES(cur ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue 1: BatchNorm batch statistics from the fp32 accumulators
   // C/D layout of 32x32: col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel)
   float* red = reinterpret_cast<float*>(smem + BM * EPI_PITCH);   // [WM][2][BN] floats, after the epilogue tile
-  constexpr bool RED_FITS = (2 * STAGE >= BM * EPI_PITCH + WM * 2 * BN * 4);
-  static_assert(RED_FITS, "no room for the stats scratch");
   if (a.stats) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -253,14 +251,13 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
 
   // ---- epilogue 3: full-line stores, 16 B (8 channels) per lane
   constexpr int OCPR = BN / 8;
-  constexpr int OPASSES = BM * OCPR / 256;
-  static_assert(OPASSES >= 1, "epilogue mapping");
+  constexpr int OPASSES = (BM * OCPR + 255) / 256;
 #pragma unroll
   for (int i = 0; i < OPASSES; ++i) {
     const int idx = tid + i * 256;
     const int row = idx / OCPR, cc = idx - row * OCPR;
     const int m = m0 + row;
-    if (m < a.M) {
+    if (row < BM && m < a.M) {
       const int pq = a.P * a.Q;
       const int n = m / pq, rem = m - n * pq;
       const int p = rem / a.Q, q = rem - p * a.Q;
@@ -287,9 +284,11 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
 template <int BM, int BN, int BK, int WM, int WN>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
+  constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
-  const size_t lds = 2 * STAGE;
+  const size_t lds = 2 * STAGE > EPI ? 2 * STAGE : EPI;
   auto kern = k_conv_gemm<BM, BN, BK, WM, WN>;
   if (lds > 64 * 1024) {
     static bool once = false;

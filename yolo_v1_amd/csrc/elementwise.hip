@@ -1,0 +1,751 @@
+// BatchNorm (training mode) forward/backward, pooling, the sigmoid head and weight re-layout for
+// gfx950.  All HBM-bound: every kernel moves 16 B (8 bf16 channels) per lane along the contiguous
+// NHWC channel axis, keeps per-channel vectors in registers and reduces over pixels with
+// column-parallel accumulators (no atomics; partial rows are summed in a fixed order).
+//
+// Replaces the ATen/cuDNN kernels behind nn.BatchNorm2d / nn.ReLU / residual add
+// (backbones/OriginResNet.py:90-105, :174-177, :187; backbones/OriginDenseNet.py:22-27, :50-51,
+// :125), nn.MaxPool2d(3,2,1) (OriginResNet.py:125, OriginDenseNet.py:80), nn.AvgPool2d(2,2)
+// (OriginDenseNet.py:54) and torch.sigmoid + permute (OriginResNet.py:188-189).
+//
+// Training-mode BN is split so that no extra pass over the activation is spent on statistics:
+//   conv epilogue  -> per-tile partial (sum, sumsq)            (csrc/conv.hip)
+//   yv1_bn_finalize-> mean, invstd, scale=g*invstd, shift=b-mean*scale, running stats
+//   yv1_bn_apply   -> z = relu?(scale*y + shift [+ residual | + rscale*res + rshift])
+// Backward:  yv1_bn_bwd_reduce (sum dyh, sum dyh*xhat, relu mask recomputed from z or from
+// scale*y+shift) -> yv1_bn_bwd_finalize (dgamma, dbeta, coefficients) -> yv1_bn_bwd_apply.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = __uint_as_float(v[k] << 16);
+    f[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = pack_bf16x2(f[2 * k], f[2 * k + 1]);
+  return v;
+}
+__device__ __forceinline__ void load8f(const float* p, float* f) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// ------------------------------------------------------------------ row reduction of partials
+// in [rows][W] -> out [gridDim.y][W], each block-row sums RB consecutive rows (fixed order).
+__global__ void k_reduce_rows(const float* __restrict__ in, float* __restrict__ out, int rows, int W, int RB) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= W) return;
+  const int r0 = blockIdx.y * RB, r1 = min(rows, r0 + RB);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += in[(size_t)r * W + c]; s1 += in[(size_t)(r + 1) * W + c];
+    s2 += in[(size_t)(r + 2) * W + c]; s3 += in[(size_t)(r + 3) * W + c];
+  }
+  for (; r < r1; ++r) s0 += in[(size_t)r * W + c];
+  out[(size_t)blockIdx.y * W + c] = (s0 + s1) + (s2 + s3);
+}
+
+// partial (sum, sumsq) rows [rows][2][Cseg] -> one row inside a wider [2][ldo] table at channel c0
+__global__ void k_stats_merge(const float* __restrict__ in, int rows, int Cseg, float* __restrict__ out, int ldo, int c0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * Cseg) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += in[(size_t)r * 2 * Cseg + i];
+  const int half = i / Cseg, c = i - half * Cseg;
+  out[(size_t)half * ldo + c0 + c] = s;
+}
+
+// ------------------------------------------------------------------ BN forward finalize
+__global__ void k_bn_finalize(const float* __restrict__ part, int rows, int C, int ldp, float count,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                              float* running_mean, float* running_var, float* __restrict__ mean_out,
+                              float* __restrict__ invstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, ss = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    s += part[(size_t)r * 2 * ldp + c];
+    ss += part[(size_t)r * 2 * ldp + ldp + c];
+  }
+  const float mean = s / count;
+  float var = ss / count - mean * mean;
+  var = var < 0.f ? 0.f : var;
+  const float invstd = rsqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_out[c] = mean;
+  invstd_out[c] = invstd;
+  scale_out[c] = g * invstd;
+  shift_out[c] = b - mean * g * invstd;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+  }
+}
+
+// eval mode: scale/shift from running statistics
+__global__ void k_bn_eval_coeffs(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                 float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = rsqrtf(rv[c] + eps);
+  scale_out[c] = gamma[c] * invstd;
+  shift_out[c] = beta[c] - rm[c] * gamma[c] * invstd;
+}
+
+// ------------------------------------------------------------------ BN apply (+ReLU, +residual)
+struct ApplyArgs {
+  const bf16_t* y; int ldy;
+  bf16_t* z; int ldz;
+  const bf16_t* res; int ldr;     // residual (nullable)
+  const float* scale; const float* shift;
+  const float* rscale; const float* rshift;   // when set, residual is a raw conv output with its own BN
+  long long npix; int C; int relu;
+};
+
+__global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
+  const int CH = a.C >> 3;
+  const long long total = a.npix * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i / CH;
+    const int cc = (int)(i - pix * CH) * 8;
+    float f[8], sc[8], sh[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.y + pix * a.ldy + cc), f);
+    load8f(a.scale + cc, sc);
+    load8f(a.shift + cc, sh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = f[k] * sc[k] + sh[k];
+    if (a.res) {
+      float r[8];
+      unpack8(*reinterpret_cast<const u32x4*>(a.res + pix * a.ldr + cc), r);
+      if (a.rscale) {
+        float rs[8], rh[8];
+        load8f(a.rscale + cc, rs);
+        load8f(a.rshift + cc, rh);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = r[k] * rs[k] + rh[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] += r[k];
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
+    }
+    *reinterpret_cast<u32x4*>(a.z + pix * a.ldz + cc) = pack8(f);
+  }
+}
+
+// ------------------------------------------------------------------ column-parallel pixel reductions
+// Thread layout: TX threads across 16-B channel chunks (TX = pow2 <= CH), TY = 256/TX pixel lanes;
+// a thread owns chunk columns tx and tx+TX (CH < 2*TX).  Per-block partial rows go to
+// out[blockIdx.x][NV][C].
+template <int NV>
+__device__ __forceinline__ void block_column_reduce(float (&acc)[2][NV][8], int tx, int ty, int TX, int TY, int CH, int C,
+                                                    float* __restrict__ out_row) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [TY][NV][C]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = tx + j * TX;
+    if (col < CH) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[((size_t)ty * NV + v) * C + col * 8 + k] = acc[j][v][k];
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NV * C; idx += 256) {
+    float s = 0.f;
+    for (int t = 0; t < TY; ++t) s += red[(size_t)t * NV * C + idx];
+    out_row[idx] = s;
+  }
+}
+
+struct StatsArgs {
+  const bf16_t* y; int ldy; long long npix; int C; int pix_per_block; float* part;  // [blocks][2][C]
+};
+
+__global__ void __launch_bounds__(256) k_bn_stats(StatsArgs a, int TX) {
+  const int CH = a.C >> 3, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  float acc[2][2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[j][v][k] = 0.f;
+  const long long p0 = (long long)blockIdx.x * a.pix_per_block;
+  const long long p1 = min(a.npix, p0 + a.pix_per_block);
+  for (long long p = p0 + ty; p < p1; p += TY) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = tx + j * TX;
+      if (col < CH) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + col * 8), f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc[j][0][k] += f[k]; acc[j][1][k] += f[k] * f[k]; }
+      }
+    }
+  }
+  block_column_reduce<2>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
+}
+
+struct BwdArgs {
+  const bf16_t* dz; int lddz;      // grad wrt BN(+ReLU) output
+  const bf16_t* z; int ldz;        // output (ReLU mask), used when mask_mode == 1
+  const bf16_t* y; int ldy;        // BN input (raw conv output)
+  const float* mean; const float* invstd; const float* scale; const float* shift;
+  long long npix; int C; int pix_per_block;
+  int mask_mode;                   // 0 none, 1 z > 0, 2 scale*y+shift > 0
+  float* part;                     // reduce: [blocks][2][C]  (sum dyh, sum dyh*xhat)
+  // apply:
+  const float* k1; const float* k2; const float* k3;   // dy = k1*dyh - k2 - xhat*k3 ... see finalize
+  bf16_t* dy; int lddy;
+  bf16_t* dres; int lddres;        // optional: masked dz copied out (identity shortcut gradient)
+  int accumulate;                  // dy += result (DenseNet: several consumers of one feature map)
+};
+
+__device__ __forceinline__ void masked_grad(const BwdArgs& a, long long p, int c8, const float* yv, float* g) {
+  unpack8(*reinterpret_cast<const u32x4*>(a.dz + p * a.lddz + c8), g);
+  if (a.mask_mode == 1) {
+    float zv[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.z + p * a.ldz + c8), zv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = zv[k] > 0.f ? g[k] : 0.f;
+  } else if (a.mask_mode == 2) {
+    float sc[8], sh[8];
+    load8f(a.scale + c8, sc);
+    load8f(a.shift + c8, sh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = (yv[k] * sc[k] + sh[k]) > 0.f ? g[k] : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
+  const int CH = a.C >> 3, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  float acc[2][2][8];
+  float mu[2][8], is[2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = tx + j * TX;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { acc[j][0][k] = 0.f; acc[j][1][k] = 0.f; mu[j][k] = 0.f; is[j][k] = 0.f; }
+    if (col < CH) { load8f(a.mean + col * 8, mu[j]); load8f(a.invstd + col * 8, is[j]); }
+  }
+  const long long p0 = (long long)blockIdx.x * a.pix_per_block;
+  const long long p1 = min(a.npix, p0 + a.pix_per_block);
+  for (long long p = p0 + ty; p < p1; p += TY) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = tx + j * TX;
+      if (col < CH) {
+        float yv[8], g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + col * 8), yv);
+        masked_grad(a, p, col * 8, yv, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          acc[j][0][k] += g[k];
+          acc[j][1][k] += g[k] * (yv[k] - mu[j][k]) * is[j][k];
+        }
+      }
+    }
+  }
+  block_column_reduce<2>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
+}
+
+// dgamma = sum dyh*xhat, dbeta = sum dyh;  dy = k1*dyh - k2 - xhat*k3 with
+// k1 = gamma*invstd, k2 = k1*dbeta/n, k3 = k1*dgamma/n
+__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int rows, int C, float count,
+                                  const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k1,
+                                  float* __restrict__ k2, float* __restrict__ k3) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, sx = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    s += part[(size_t)r * 2 * C + c];
+    sx += part[(size_t)r * 2 * C + C + c];
+  }
+  if (dgamma) dgamma[c] = sx;
+  if (dbeta) dbeta[c] = s;
+  const float g = gamma ? gamma[c] : 1.f;
+  const float a1 = g * invstd[c];
+  k1[c] = a1;
+  k2[c] = a1 * s / count;
+  k3[c] = a1 * sx / count;
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
+  const int CH = a.C >> 3;
+  const long long total = a.npix * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i / CH;
+    const int c8 = (int)(i - p * CH) * 8;
+    float yv[8], g[8], mu[8], is[8], k1[8], k2[8], k3[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8), yv);
+    masked_grad(a, p, c8, yv, g);
+    if (a.dres) *reinterpret_cast<u32x4*>(a.dres + p * a.lddres + c8) = pack8(g);
+    load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
+    load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = k1[k] * g[k] - k2[k] - (yv[k] - mu[k]) * is[k] * k3[k];
+    if (a.accumulate) {
+      float old[8];
+      unpack8(*reinterpret_cast<const u32x4*>(a.dy + p * a.lddy + c8), old);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += old[k];
+    }
+    *reinterpret_cast<u32x4*>(a.dy + p * a.lddy + c8) = pack8(o);
+  }
+}
+
+// ------------------------------------------------------------------ max pool 3x3 / stride 2 / pad 1
+__global__ void __launch_bounds__(256) k_maxpool_fwd(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                                     int N, int H, int W, int C) {
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1, CH = C >> 3;
+  const long long total = (long long)N * OH * OW * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % CH) * 8;
+    long long t = i / CH;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+    for (int r = 0; r < 3; ++r) {
+      const int h = oh * 2 - 1 + r;
+      if (h < 0 || h >= H) continue;
+      for (int s = 0; s < 3; ++s) {
+        const int w = ow * 2 - 1 + s;
+        if (w < 0 || w >= W) continue;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)(n * H + h) * W + w) * ldx + cc), f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], f[k]);
+      }
+    }
+    *reinterpret_cast<u32x4*>(y + ((size_t)(n * OH + oh) * OW + ow) * ldy + cc) = pack8(m);
+  }
+}
+
+// gather form: every input pixel collects the gradient of each window whose FIRST maximum (row-major
+// scan, the element torch's max_pool2d backward selects) it is.
+__global__ void __launch_bounds__(256) k_maxpool_bwd(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy,
+                                                     int lddy, bf16_t* __restrict__ dx, int lddx, int N, int H, int W, int C) {
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1, CH = C >> 3;
+  const long long total = (long long)N * H * W * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % CH) * 8;
+    long long t = i / CH;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float me[8], g[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)(n * H + h) * W + w) * ldx + cc), me);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = 0.f;
+    // windows (oh,ow) containing (h,w): oh*2-1 <= h <= oh*2+1
+    const int oh_lo = max(0, (h) / 2), oh_hi = min(OH - 1, (h + 1) / 2);
+    const int ow_lo = max(0, (w) / 2), ow_hi = min(OW - 1, (w + 1) / 2);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        // is (h,w) the first max of window (oh,ow)?
+        bool first[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) first[k] = true;
+        for (int r = 0; r < 3; ++r) {
+          const int hh = oh * 2 - 1 + r;
+          if (hh < 0 || hh >= H) continue;
+          for (int s = 0; s < 3; ++s) {
+            const int ww = ow * 2 - 1 + s;
+            if (ww < 0 || ww >= W || (hh == h && ww == w)) continue;
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)(n * H + hh) * W + ww) * ldx + cc), f);
+            const bool before = (hh < h) || (hh == h && ww < w);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) first[k] = first[k] && (before ? (f[k] < me[k]) : (f[k] <= me[k]));
+          }
+        }
+        float d[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dy + ((size_t)(n * OH + oh) * OW + ow) * lddy + cc), d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] += first[k] ? d[k] : 0.f;
+      }
+    *reinterpret_cast<u32x4*>(dx + ((size_t)(n * H + h) * W + w) * lddx + cc) = pack8(g);
+  }
+}
+
+// ------------------------------------------------------------------ average pool 2x2 / stride 2
+__global__ void __launch_bounds__(256) k_avgpool_fwd(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                                     int N, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2, CH = C >> 3;
+  const long long total = (long long)N * OH * OW * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % CH) * 8;
+    long long t = i / CH;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    for (int r = 0; r < 2; ++r)
+      for (int q = 0; q < 2; ++q) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)(n * H + oh * 2 + r) * W + ow * 2 + q) * ldx + cc), f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += f[k];
+      }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] *= 0.25f;
+    *reinterpret_cast<u32x4*>(y + ((size_t)(n * OH + oh) * OW + ow) * ldy + cc) = pack8(s);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_avgpool_bwd(const bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dx, int lddx,
+                                                     int N, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2, CH = C >> 3;
+  const long long total = (long long)N * H * W * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % CH) * 8;
+    long long t = i / CH;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = 0.f;
+    if (h / 2 < OH && w / 2 < OW) {
+      unpack8(*reinterpret_cast<const u32x4*>(dy + ((size_t)(n * OH + h / 2) * OW + w / 2) * lddy + cc), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] *= 0.25f;
+    }
+    *reinterpret_cast<u32x4*>(dx + ((size_t)(n * H + h) * W + w) * lddx + cc) = pack8(f);
+  }
+}
+
+// ------------------------------------------------------------------ head: bn_end + sigmoid
+// y [npix][ldy] bf16 (first C channels valid) -> out [npix][C] fp32 = sigmoid(scale*y + shift)
+__global__ void k_head_fwd(const bf16_t* __restrict__ y, int ldy, const float* __restrict__ scale,
+                           const float* __restrict__ shift, float* __restrict__ out, long long npix, int C) {
+  const long long total = npix * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    const float v = bf16_to_f32(y[p * ldy + c]) * scale[c] + shift[c];
+    out[i] = 1.f / (1.f + __expf(-v));
+  }
+}
+
+// one workgroup per channel: sigmoid backward + BN backward (reduce and apply fused; the head is tiny)
+__global__ void __launch_bounds__(256) k_head_bwd(const float* __restrict__ dout, const float* __restrict__ out,
+                                                  const bf16_t* __restrict__ y, int ldy, const float* __restrict__ gamma,
+                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                  bf16_t* __restrict__ dy, int lddy, float* __restrict__ dgamma,
+                                                  float* __restrict__ dbeta, long long npix, int C) {
+  __shared__ float red[2][4];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (c >= C) {   // padding channels of the 32-wide head buffer carry no gradient
+    for (long long p = threadIdx.x; p < npix; p += 256) dy[p * lddy + c] = 0;
+    return;
+  }
+  const float mu = mean[c], is = invstd[c];
+  float s = 0.f, sx = 0.f;
+  for (long long p = threadIdx.x; p < npix; p += 256) {
+    const float o = out[p * C + c];
+    const float g = dout[p * C + c] * o * (1.f - o);
+    s += g;
+    sx += g * (bf16_to_f32(y[p * ldy + c]) - mu) * is;
+  }
+  s = wave_sum(s); sx = wave_sum(sx);
+  if (lane == 0) { red[0][wid] = s; red[1][wid] = sx; }
+  __syncthreads();
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  sx = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  if (threadIdx.x == 0) { dgamma[c] = sx; dbeta[c] = s; }
+  const float k1 = gamma[c] * is, n = (float)npix;
+  for (long long p = threadIdx.x; p < npix; p += 256) {
+    const float o = out[p * C + c];
+    const float g = dout[p * C + c] * o * (1.f - o);
+    const float xh = (bf16_to_f32(y[p * ldy + c]) - mu) * is;
+    dy[p * lddy + c] = f32_to_bf16(k1 * (g - s / n - xh * sx / n));
+  }
+}
+
+// ------------------------------------------------------------------ weight re-layout
+// src: fp32 OIHW tensor with arbitrary element strides; dst_fwd [Opad][taps][Ipad] bf16 and
+// (optionally) dst_t [Ipad][taps][Opad] bf16 (the dgrad operand).  Padding rows/cols are zero.
+__global__ void k_prep_weights(const float* __restrict__ w, long long so, long long si, long long sh, long long sw, int O,
+                               int I, int KH, int KW, int Opad, int Ipad, bf16_t* __restrict__ dst_fwd,
+                               bf16_t* __restrict__ dst_t) {
+  const int taps = KH * KW;
+  const long long total = (long long)Opad * taps * Ipad;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % Ipad);
+    long long t = idx / Ipad;
+    const int tap = (int)(t % taps);
+    const int o = (int)(t / taps);
+    float v = 0.f;
+    if (o < O && i < I) v = w[o * so + i * si + (tap / KW) * sh + (tap % KW) * sw];
+    const bf16_t b = f32_to_bf16(v);
+    dst_fwd[idx] = b;
+    if (dst_t) dst_t[((size_t)i * taps + tap) * Opad + o] = b;
+  }
+}
+
+// stem: fp32 [O][3][7][7] (any strides) -> bf16 [O][7][32], element s*4+c of filter row r
+__global__ void k_prep_stem(const float* __restrict__ w, long long so, long long si, long long sh, long long sw, int O,
+                            bf16_t* __restrict__ dst) {
+  const int total = O * 7 * 32;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx % 32, r = (idx / 32) % 7, o = idx / (32 * 7);
+    const int s = e >> 2, c = e & 3;
+    float v = 0.f;
+    if (s < 7 && c < 3) v = w[o * so + c * si + r * sh + s * sw];
+    dst[idx] = f32_to_bf16(v);
+  }
+}
+
+// stem gradient back: fp32 [O][7][32] -> fp32 [O][3][7][7] with the parameter's strides
+__global__ void k_unpack_stem_grad(const float* __restrict__ g, float* __restrict__ dw, long long so, long long si,
+                                   long long sh, long long sw, int O) {
+  const int total = O * 3 * 7 * 7;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int s = idx % 7, r = (idx / 7) % 7, c = (idx / 49) % 3, o = idx / 147;
+    dw[o * so + c * si + r * sh + s * sw] = g[(o * 7 + r) * 32 + s * 4 + c];
+  }
+}
+
+int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+int ew_blocks(long long total) { long long b = (total + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+// ---- partial-row helpers ---------------------------------------------------------------------
+// Sums groups of RB rows of a [rows][W] fp32 matrix: out[ceil(rows/RB)][W].
+extern "C" int yv1_reduce_rows(const float* in, float* out, int rows, int W, int RB, hipStream_t stream) {
+  if (!in || !out || rows <= 0 || W <= 0 || RB <= 0) return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_reduce_rows, dim3((W + 127) / 128, (rows + RB - 1) / RB), dim3(128), 0, stream, in, out, rows, W, RB);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+// Folds partial statistic rows [rows][2][Cseg] into row form inside table [2][ldo] at channel c0
+// (DenseNet: one statistics table per dense block, filled as each 32-channel slice is produced).
+extern "C" int yv1_stats_merge(const float* partials, int rows, int Cseg, float* table, int ldo, int c0, hipStream_t stream) {
+  if (!partials || !table || rows <= 0 || Cseg <= 0 || c0 < 0 || c0 + Cseg > ldo) return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_stats_merge, dim3((2 * Cseg + 63) / 64), dim3(64), 0, stream, partials, rows, Cseg, table, ldo, c0);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_bn_finalize(const float* partials, int rows, int C, int ld_partials, float count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                               float* mean, float* invstd, float* scale, float* shift, hipStream_t stream) {
+  if (!partials || rows <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partials, rows, C, ld_partials, count, gamma,
+                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, hipStream_t stream) {
+  if (C <= 0 || !gamma || !beta || !running_mean || !running_var || !scale || !shift) return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_bn_eval_coeffs, dim3((C + 63) / 64), dim3(64), 0, stream, C, gamma, beta, running_mean, running_var,
+                     eps, scale, shift);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_bn_apply(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
+                            const float* shift, const float* res_scale, const float* res_shift, long long npix, int C,
+                            int relu, hipStream_t stream) {
+  if (!y || !z || !scale || !shift || npix <= 0 || C <= 0) return YV1_ERR_BAD_ARG;
+  if (C % 8 || ldy % 8 || ldz % 8 || (residual && ldr % 8)) return YV1_ERR_UNSUPPORTED;
+  ApplyArgs a;
+  a.y = (const bf16_t*)y; a.ldy = ldy; a.z = (bf16_t*)z; a.ldz = ldz; a.res = (const bf16_t*)residual; a.ldr = ldr;
+  a.scale = scale; a.shift = shift; a.rscale = res_scale; a.rshift = res_shift; a.npix = npix; a.C = C; a.relu = relu;
+  hipLaunchKernelGGL(k_bn_apply, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+// number of partial rows yv1_bn_stats / yv1_bn_bwd_reduce write for npix pixels
+extern "C" int yv1_bn_reduce_rows(long long npix, int C) {
+  const int CH = C / 8;
+  const int TX = floor_pow2(CH < 256 ? CH : 256), TY = 256 / TX;
+  long long ppb = (long long)TY * 64;                 // 64 pixel iterations per thread
+  long long blocks = (npix + ppb - 1) / ppb;
+  while (blocks > 2048) { ppb *= 2; blocks = (npix + ppb - 1) / ppb; }
+  return (int)blocks;
+}
+
+static int reduce_geometry(long long npix, int C, int* TX, int* ppb, int* blocks, size_t* lds) {
+  if (C % 8 || C > 4096) return YV1_ERR_UNSUPPORTED;
+  const int CH = C / 8;
+  *TX = floor_pow2(CH < 256 ? CH : 256);
+  if (CH >= 2 * *TX) return YV1_ERR_UNSUPPORTED;
+  const int TY = 256 / *TX;
+  long long p = (long long)TY * 64;
+  long long b = (npix + p - 1) / p;
+  while (b > 2048) { p *= 2; b = (npix + p - 1) / p; }
+  *ppb = (int)p; *blocks = (int)b;
+  *lds = (size_t)TY * 2 * C * sizeof(float);
+  return YV1_OK;
+}
+
+// stand-alone batch statistics: partials [yv1_bn_reduce_rows(npix,C)][2][C]
+extern "C" int yv1_bn_stats(const void* y, int ldy, long long npix, int C, float* partials, hipStream_t stream) {
+  if (!y || !partials || npix <= 0) return YV1_ERR_BAD_ARG;
+  int TX, ppb, blocks; size_t lds;
+  int rc = reduce_geometry(npix, C, &TX, &ppb, &blocks, &lds);
+  if (rc) return rc;
+  if (ldy % 8) return YV1_ERR_UNSUPPORTED;
+  StatsArgs a; a.y = (const bf16_t*)y; a.ldy = ldy; a.npix = npix; a.C = C; a.pix_per_block = ppb; a.part = partials;
+  hipLaunchKernelGGL(k_bn_stats, dim3(blocks), dim3(256), lds, stream, a, TX);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_bn_bwd_reduce(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, long long npix, int C,
+                                 int mask_mode, float* partials, hipStream_t stream) {
+  if (!dz || !y || !mean || !invstd || !partials || npix <= 0) return YV1_ERR_BAD_ARG;
+  if ((mask_mode == 1 && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
+  int TX, ppb, blocks; size_t lds;
+  int rc = reduce_geometry(npix, C, &TX, &ppb, &blocks, &lds);
+  if (rc) return rc;
+  if (lddz % 8 || ldy % 8 || (z && ldz % 8)) return YV1_ERR_UNSUPPORTED;
+  BwdArgs a = {};
+  a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
+  a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.npix = npix; a.C = C; a.pix_per_block = ppb;
+  a.mask_mode = mask_mode; a.part = partials;
+  hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(blocks), dim3(256), lds, stream, a, TX);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_bn_bwd_finalize(const float* partials, int rows, int C, float count, const float* gamma,
+                                   const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                                   hipStream_t stream) {
+  if (!partials || rows <= 0 || C <= 0 || !invstd || !k1 || !k2 || !k3) return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partials, rows, C, count, gamma, invstd,
+                     dgamma, dbeta, k1, k2, k3);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                                const float* invstd, const float* scale, const float* shift, const float* k1,
+                                const float* k2, const float* k3, long long npix, int C, int mask_mode, void* dy, int lddy,
+                                void* dres, int lddres, int accumulate, hipStream_t stream) {
+  if (!dz || !y || !mean || !invstd || !k1 || !k2 || !k3 || !dy || npix <= 0) return YV1_ERR_BAD_ARG;
+  if ((mask_mode == 1 && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
+  if (C % 8 || lddz % 8 || ldy % 8 || lddy % 8 || (z && ldz % 8) || (dres && lddres % 8)) return YV1_ERR_UNSUPPORTED;
+  BwdArgs a = {};
+  a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
+  a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.npix = npix; a.C = C; a.mask_mode = mask_mode;
+  a.k1 = k1; a.k2 = k2; a.k3 = k3; a.dy = (bf16_t*)dy; a.lddy = lddy; a.dres = (bf16_t*)dres; a.lddres = lddres;
+  a.accumulate = accumulate;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, hipStream_t stream) {
+  if (!x || !y || N <= 0 || C % 8 || ldx % 8 || ldy % 8) return YV1_ERR_BAD_ARG;
+  const long long total = (long long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 8);
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, H, W, C);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_maxpool3x3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W,
+                                    int C, hipStream_t stream) {
+  if (!x || !dy || !dx || N <= 0 || C % 8 || ldx % 8 || lddy % 8 || lddx % 8) return YV1_ERR_BAD_ARG;
+  const long long total = (long long)N * H * W * (C / 8);
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
+                     (bf16_t*)dx, lddx, N, H, W, C);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_avgpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, hipStream_t stream) {
+  if (!x || !y || N <= 0 || C % 8 || ldx % 8 || ldy % 8) return YV1_ERR_BAD_ARG;
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(k_avgpool_fwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, H, W, C);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_avgpool2_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, hipStream_t stream) {
+  if (!dy || !dx || N <= 0 || C % 8 || lddy % 8 || lddx % 8) return YV1_ERR_BAD_ARG;
+  const long long total = (long long)N * H * W * (C / 8);
+  hipLaunchKernelGGL(k_avgpool_bwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, H, W, C);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_head_sigmoid_fwd(const void* y, int ldy, const float* scale, const float* shift, float* out,
+                                    long long npix, int C, hipStream_t stream) {
+  if (!y || !scale || !shift || !out || npix <= 0 || C <= 0) return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_head_fwd, dim3(ew_blocks(npix * C)), dim3(256), 0, stream, (const bf16_t*)y, ldy, scale, shift, out, npix, C);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+// dy gets lddy channels written (channels >= C zeroed)
+extern "C" int yv1_head_sigmoid_bwd(const float* dout, const float* out, const void* y, int ldy, const float* gamma,
+                                    const float* mean, const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta,
+                                    long long npix, int C, hipStream_t stream) {
+  if (!dout || !out || !y || !gamma || !mean || !invstd || !dy || !dgamma || !dbeta || npix <= 0 || C <= 0 || lddy < C)
+    return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_head_bwd, dim3(lddy), dim3(256), 0, stream, dout, out, (const bf16_t*)y, ldy, gamma, mean, invstd,
+                     (bf16_t*)dy, lddy, dgamma, dbeta, npix, C);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_prep_weights(const float* w, long long so, long long si, long long sh, long long sw, int O, int I, int KH,
+                                int KW, int Opad, int Ipad, void* dst_fwd, void* dst_t, hipStream_t stream) {
+  if (!w || !dst_fwd || O <= 0 || I <= 0 || Opad < O || Ipad < I) return YV1_ERR_BAD_ARG;
+  const long long total = (long long)Opad * KH * KW * Ipad;
+  hipLaunchKernelGGL(k_prep_weights, dim3(ew_blocks(total)), dim3(256), 0, stream, w, so, si, sh, sw, O, I, KH, KW, Opad, Ipad,
+                     (bf16_t*)dst_fwd, (bf16_t*)dst_t);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_prep_stem_weights(const float* w, long long so, long long si, long long sh, long long sw, int O, void* dst,
+                                     hipStream_t stream) {
+  if (!w || !dst || O <= 0) return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_prep_stem, dim3(ew_blocks((long long)O * 224)), dim3(256), 0, stream, w, so, si, sh, sw, O, (bf16_t*)dst);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_unpack_stem_grad(const float* g, float* dw, long long so, long long si, long long sh, long long sw, int O,
+                                    hipStream_t stream) {
+  if (!g || !dw || O <= 0) return YV1_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_unpack_stem_grad, dim3(ew_blocks((long long)O * 147)), dim3(256), 0, stream, g, dw, so, si, sh, sw, O);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}

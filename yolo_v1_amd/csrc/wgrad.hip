@@ -1,0 +1,310 @@
+// Convolution weight gradient on MFMA for gfx950 (MI355X / CDNA4).
+//
+// Replaces the cuDNN wgrad behind every nn.Conv2d of the reference backbones
+// (backbones/OriginResNet.py:21-29,:121,:159-163; backbones/OriginDenseNet.py:24-29,:52-53) that
+// `loss.backward()` runs at train.py:171.
+//
+// GEMM view:  dW[k][tap][c] = sum_m dY[m][k] * Xg[m,tap][c]
+//   rows  = output channel k, cols = input channel c (one tap per workgroup), reduction = pixels m.
+// Both operands live in HBM pixel-major (NHWC: channels contiguous), but MFMA wants the reduction
+// index (pixels) along each lane's 8-element fragment.  The tiles are staged pixel-major into LDS
+// with full 16-B channel runs (coalesced) and read back TRANSPOSED with ds_read_b64_tr_b16, the
+// CDNA4 hardware transpose read: no shuffles, no scalar LDS reads.  LDS rows are padded by 64 B so
+// the four pixel rows a transposed read touches fall on disjoint bank quarters.
+// The pixel reduction is split over workgroups (split-K); each split writes an fp32 slab with plain
+// stores and a second tiny kernel sums the slabs in a fixed order -- bitwise reproducible, no float
+// atomics (which run at ~1/5 of the store rate on this chip).
+// The result layout [Cout][taps][Cin] fp32 is exactly the channels_last storage of the OIHW
+// parameter's .grad, so the optimizer consumes it without a layout pass.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short short4_;
+
+struct WgradArgs {
+  const bf16_t* X;    // [N,IH,IW,*] pixel stride ldx
+  const bf16_t* DY;   // [N,P,Q,*]   pixel stride lddy
+  float* OUT;         // slabs [splitK][Cout][taps][Cin] (or the final tensor when splitK == 1)
+  int N, IH, IW, ldx, P, Q, lddy;
+  int Cin, Cout, R, S;
+  int ah, bh, ch, aw, bw, cw;   // ih = p*ah + r*bh + ch   (forward tap map)
+  int M;                        // N*P*Q
+  int splitK, steps_per_split;  // K-steps (of 32 pixels) per split
+  int CT, KT;                   // cin tiles, cout tiles
+};
+
+constexpr int KP = 32;  // pixels per K-step
+
+__device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) short4_ lds_s4;
+  short4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+template <int BMC, int BNC, int WM, int WN>
+__global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
+  constexpr int PA = BMC * 2 + 64, PB = BNC * 2 + 64;     // LDS row pitches (bytes)
+  constexpr int A_BYTES = KP * PA, B_BYTES = KP * PB;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int ACH = BMC / 8, BCH = BNC / 8;             // 16-B chunks per pixel row
+  constexpr int A_PASSES = (KP * ACH + 255) / 256, B_PASSES = (KP * BCH + 255) / 256;
+  constexpr int TM = BMC / WM / 32, TN = BNC / WN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+
+  // block -> (split, cout tile, cin tile, tap): taps innermost so the blocks that re-read the same
+  // dY / X pixel range are launched together
+  int b = blockIdx.x;
+  const int taps = a.R * a.S;
+  const int tap = b % taps; b /= taps;
+  const int ct = b % a.CT; b /= a.CT;
+  const int kt_ = b % a.KT; b /= a.KT;
+  const int split = b;
+  const int r = tap / a.S, s = tap - r * a.S;
+  const int k0 = kt_ * BMC, c0 = ct * BNC;
+
+  const int step0 = split * a.steps_per_split;
+  const int total_steps = (a.M + KP - 1) / KP;
+  const int nsteps = min(a.steps_per_split, total_steps - step0);
+
+  uint4 ra[A_PASSES], rb[B_PASSES];
+  const int PQ = a.P * a.Q;
+
+  auto load_tiles = [&](int step) {
+    const int mbase = (step0 + step) * KP;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / ACH, cc = idx - row * ACH;
+      const int m = mbase + row;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (row < KP && m < a.M && k0 + cc * 8 < a.Cout)
+        ra[i] = *reinterpret_cast<const uint4*>(a.DY + (size_t)m * a.lddy + k0 + cc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / BCH, cc = idx - row * BCH;
+      const int m = mbase + row;
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (row < KP && m < a.M) {
+        const int n = m / PQ, rem = m - n * PQ;
+        const int p = rem / a.Q, q = rem - p * a.Q;
+        const int ih = p * a.ah + r * a.bh + a.ch, iw = q * a.aw + s * a.bw + a.cw;
+        if (ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW)
+          rb[i] = *reinterpret_cast<const uint4*>(a.X + ((size_t)(n * a.IH + ih) * a.IW + iw) * a.ldx + c0 + cc * 8);
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / ACH, cc = idx - row * ACH;
+      if (row < KP) *reinterpret_cast<uint4*>(sa + row * PA + cc * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / BCH, cc = idx - row * BCH;
+      if (row < KP) *reinterpret_cast<uint4*>(sb + row * PB + cc * 16) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // transposed-read lane geometry (ds_read_b64_tr_b16): within each group of 16 lanes, lane 4q+p
+  // supplies the address of pixel row q, channels 4p..4p+3; lane i receives channel i of the 4 rows.
+  const int g = lane >> 4, li = lane & 15;
+  const int tq = li >> 2, tp = li & 3;
+  const int h = g >> 1;                               // which 8-pixel half of the 16-pixel MFMA K
+  const int chan_off = 16 * (g & 1) + 4 * tp;         // channel offset inside a 32-channel block
+
+  if (nsteps > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) load_tiles(st + 1);
+    const unsigned char* sa = smem + cur * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KP / 16; ++ks) {
+      const int prow = ks * 16 + 8 * h + tq;
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int col = wm * (BMC / WM) + i * 32 + chan_off;
+        const bf16x4 lo = lds_read_tr16(sa + prow * PA + col * 2);
+        const bf16x4 hi = lds_read_tr16(sa + (prow + 4) * PA + col * 2);
+        fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * (BNC / WN) + j * 32 + chan_off;
+        const bf16x4 lo = lds_read_tr16(sb + prow * PB + col * 2);
+        const bf16x4 hi = lds_read_tr16(sb + (prow + 4) * PB + col * 2);
+        fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D[row = cout][col = cin]; col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const int l31 = lane & 31, lh = lane >> 5;
+  const size_t Ktot = (size_t)taps * a.Cin;
+  float* out = a.OUT + (size_t)split * a.Cout * Ktot;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = c0 + wn * (BNC / WN) + j * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = k0 + wm * (BMC / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (k < a.Cout && c < a.Cin) out[(size_t)k * Ktot + (size_t)tap * a.Cin + c] = acc[i][j][e];
+      }
+    }
+}
+
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long long n, int splitK) {
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(slabs)[i];
+    for (int k = 1; k < splitK; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(slabs + (size_t)k * n)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
+  }
+}
+
+template <int BMC, int BNC, int WM, int WN>
+int launch(WgradArgs& a, int nblocks, hipStream_t stream) {
+  constexpr int STAGE = KP * (BMC * 2 + 64) + KP * (BNC * 2 + 64);
+  hipLaunchKernelGGL((k_wgrad<BMC, BNC, WM, WN>), dim3(nblocks), dim3(256), 2 * STAGE, stream, a);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+struct Plan { int bmc, bnc, KT, CT, splitK, steps; };
+
+Plan make_plan(int M, int Cin, int Cout, int taps) {
+  Plan p;
+  if (Cout % 128 == 0 && Cin % 128 == 0) { p.bmc = 128; p.bnc = 128; }
+  else if (Cout % 64 == 0 && Cin % 64 == 0) { p.bmc = 64; p.bnc = 64; }
+  else if (Cout <= 32 && Cin % 128 == 0) { p.bmc = 32; p.bnc = 128; }
+  else { p.bmc = 128; p.bnc = 32; }
+  p.KT = (Cout + p.bmc - 1) / p.bmc;
+  p.CT = (Cin + p.bnc - 1) / p.bnc;
+  const int tiles = p.KT * p.CT * taps;
+  const int total_steps = (M + KP - 1) / KP;
+  int want = (768 + tiles - 1) / tiles;             // aim for ~3 workgroups per CU
+  int maxsplit = total_steps / 16;                  // at least 16 K-steps (512 pixels) per split
+  if (maxsplit < 1) maxsplit = 1;
+  if (want > maxsplit) want = maxsplit;
+  if (want < 1) want = 1;
+  p.steps = (total_steps + want - 1) / want;
+  p.splitK = (total_steps + p.steps - 1) / p.steps;
+  return p;
+}
+
+}  // namespace
+
+extern "C" size_t yv1_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int k) {
+  const Plan p = make_plan(N * OH * OW, Cin, Cout, k * k);
+  return p.splitK > 1 ? (size_t)p.splitK * Cout * k * k * Cin * sizeof(float) : 0;
+}
+
+// dw[Cout][k*k][Cin] fp32 = sum over pixels of dy (x) x_tap.   x: [N,IH,IW,*] (pixel stride ldx),
+// dy: [N,OH,OW,*] (pixel stride lddy).  workspace: yv1_conv2d_wgrad_workspace_bytes().
+extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx,
+                                          int Cin, int Cout, int lddy, int k, int stride, int pad, void* workspace,
+                                          size_t workspace_bytes, hipStream_t stream) {
+  if (!x || !dy || !dw || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
+  if (Cin % 32 || ldx % 8 || lddy % 8 || Cout % 8) return YV1_ERR_UNSUPPORTED;
+  WgradArgs a;
+  a.X = (const bf16_t*)x; a.DY = (const bf16_t*)dy;
+  a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx;
+  a.P = (IH + 2 * pad - k) / stride + 1; a.Q = (IW + 2 * pad - k) / stride + 1; a.lddy = lddy;
+  a.Cin = Cin; a.Cout = Cout; a.R = k; a.S = k;
+  a.ah = stride; a.bh = 1; a.ch = -pad; a.aw = stride; a.bw = 1; a.cw = -pad;
+  a.M = N * a.P * a.Q;
+  const Plan p = make_plan(a.M, Cin, Cout, k * k);
+  const size_t need = p.splitK > 1 ? (size_t)p.splitK * Cout * k * k * Cin * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace)) return YV1_ERR_WORKSPACE;
+  a.splitK = p.splitK; a.steps_per_split = p.steps; a.CT = p.CT; a.KT = p.KT;
+  a.OUT = p.splitK > 1 ? (float*)workspace : dw;
+  const int nblocks = p.splitK * p.KT * p.CT * k * k;
+  int rc;
+  if (p.bmc == 128 && p.bnc == 128) rc = launch<128, 128, 2, 2>(a, nblocks, stream);
+  else if (p.bmc == 64) rc = launch<64, 64, 2, 2>(a, nblocks, stream);
+  else if (p.bmc == 32) rc = launch<32, 128, 1, 4>(a, nblocks, stream);
+  else rc = launch<128, 32, 4, 1>(a, nblocks, stream);
+  if (rc) return rc;
+  if (p.splitK > 1) {
+    const long long n = (long long)Cout * k * k * Cin;
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, p.splitK);
+    YV1_LAUNCH_CHECK();
+  }
+  return YV1_OK;
+}
+
+// Stem weight gradient: x is the packed NHWC4 image [N][H+6][W+6][4]; dw comes out as [Cout][7][32]
+// (element s*4+c of filter row r), the layout yv1_conv2d_stem_fwd_bf16 consumes.
+extern "C" size_t yv1_conv2d_stem_wgrad_workspace_bytes(int N, int H, int W, int Cout) {
+  const Plan p = make_plan(N * (H / 2) * (W / 2), 32, Cout, 7);
+  return p.splitK > 1 ? (size_t)p.splitK * Cout * 7 * 32 * sizeof(float) : 0;
+}
+
+extern "C" int yv1_conv2d_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int N, int H, int W, int Cout,
+                                          int lddy, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!xp || !dy || !dw || N <= 0 || (H & 1) || (W & 1)) return YV1_ERR_BAD_ARG;
+  WgradArgs a;
+  a.X = (const bf16_t*)xp; a.DY = (const bf16_t*)dy;
+  a.N = N; a.IH = H + 6; a.IW = W + 6; a.ldx = 4;
+  a.P = H / 2; a.Q = W / 2; a.lddy = lddy;
+  a.Cin = 32; a.Cout = Cout; a.R = 7; a.S = 1;
+  a.ah = 2; a.bh = 1; a.ch = 0; a.aw = 2; a.bw = 0; a.cw = 0;
+  a.M = N * a.P * a.Q;
+  const Plan p = make_plan(a.M, 32, Cout, 7);
+  const size_t need = p.splitK > 1 ? (size_t)p.splitK * Cout * 7 * 32 * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace)) return YV1_ERR_WORKSPACE;
+  a.splitK = p.splitK; a.steps_per_split = p.steps; a.CT = p.CT; a.KT = p.KT;
+  a.OUT = p.splitK > 1 ? (float*)workspace : dw;
+  const int nblocks = p.splitK * p.KT * p.CT * 7;
+  int rc = launch<128, 32, 4, 1>(a, nblocks, stream);
+  if (rc) return rc;
+  if (p.splitK > 1) {
+    const long long n = (long long)Cout * 7 * 32;
+    int blocks = (int)((n / 4 + 255) / 256);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, p.splitK);
+    YV1_LAUNCH_CHECK();
+  }
+  return YV1_OK;
+}

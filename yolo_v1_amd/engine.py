@@ -1,0 +1,91 @@
+"""Whole-backbone autograd node and shared executor pieces.
+
+The reference lets autograd record ~500 ATen nodes per step for the backbone
+(backbones/OriginResNet.py:173-195, OriginDenseNet.py:114-129).  Here the backbone is ONE
+autograd node: its forward runs the HIP kernels layer by layer and keeps the tensors the
+backward needs; its backward walks the layers in reverse with explicit dgrad / wgrad / BN-backward
+launches and hands every parameter gradient back to autograd in one go, so ``loss.backward()``
+and any ``torch.optim`` optimizer keep working unchanged (train.py:170-172).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+
+class ConvParam(nn.Module):
+    """Holds one bias-free convolution weight under the key ``<name>.weight`` (what
+    conv3x3/conv1x1, backbones/OriginResNet.py:21-29, contribute to the state_dict).  The
+    parameter is logically OIHW but stored channels_last, i.e. physically [O][kh][kw][I] -- the
+    layout the MFMA kernels and the weight-gradient kernel use."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.kernel_size, self.stride, self.padding = k, stride, pad
+        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        self.weight = nn.Parameter(w)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%d, stride=%d, padding=%d, bias=False" % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding)
+
+
+def make_bn(c):
+    """nn.BatchNorm2d used as the parameter/buffer container (weight, bias, running_mean,
+    running_var, num_batches_tracked keys); its own forward is never called."""
+    return nn.BatchNorm2d(c)
+
+
+class BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, images, *params):
+        _lib.require_cuda(images)
+        train = net.training
+        need_bwd = any(ctx.needs_input_grad)
+        with torch.no_grad():
+            pred, saved = net._run_forward(images, train, need_bwd)
+        ctx.net = net
+        ctx.saved = saved
+        ctx.params = params
+        return pred
+
+    @staticmethod
+    def backward(ctx, gpred):
+        net, saved = ctx.net, ctx.saved
+        ctx.saved = None
+        if saved is None:
+            raise _lib.Yv1Error("backward called twice or forward ran without saving (no_grad)")
+        with torch.no_grad():
+            grads = net._run_backward(saved, gpred)
+        out = []
+        for p in ctx.params:
+            g = grads.get(p)
+            out.append(g)
+        return (None, None) + tuple(out)
+
+
+class HipBackbone(nn.Module):
+    """Base: parameter bookkeeping shared by the ResNet and DenseNet executors."""
+
+    def __init__(self):
+        super().__init__()
+        self._convw = {}      # ConvParam -> ops.ConvWeights
+
+    def cw(self, conv, **kw):
+        w = self._convw.get(conv)
+        if w is None or w.param is not conv.weight:
+            w = ops.ConvWeights(conv.weight, conv.kernel_size, conv.stride, conv.padding, **kw)
+            self._convw[conv] = w
+        w.refresh()
+        return w
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.Yv1Error("yolo_v1_amd backbones run on the GPU only; there is no CPU fallback")
+        params = [p for p in self.parameters()]
+        return BackboneFn.apply(self, x, *params)
+
+    def _bump_counters(self, bns):
+        # num_batches_tracked += 1 for every BatchNorm that ran in training mode
+        torch._foreach_add_([b.num_batches_tracked for b in bns], 1)

@@ -1,0 +1,293 @@
+"""Thin host wrappers over the C-ABI kernels (include/yv1.h).
+
+An activation is an NHWC bf16 torch tensor plus a channel window (``Act``): kernels take a base
+pointer and a pixel stride, so a DenseNet block's growing feature map is ONE buffer and every
+layer writes its 32-channel slice in place -- ``torch.cat`` (OriginDenseNet.py:36) disappears.
+torch only owns the memory and the stream.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Act:
+    """NHWC bf16 activation window: channels [c0, c0+C) of tensor ``t`` [N,H,W,Ctot]."""
+    __slots__ = ("t", "c0", "C", "N", "H", "W", "ld", "p")
+
+    def __init__(self, t, c0=0, C=None):
+        self.t = t
+        self.N, self.H, self.W, self.ld = t.shape
+        self.c0 = c0
+        self.C = self.ld - c0 if C is None else C
+        self.p = t.data_ptr() + 2 * c0
+
+    @property
+    def npix(self):
+        return self.N * self.H * self.W
+
+    def window(self, c0, C):
+        return Act(self.t, self.c0 + c0, C)
+
+
+def new_act(N, H, W, C, device):
+    return Act(torch.empty((N, H, W, C), dtype=torch.bfloat16, device=device))
+
+
+def _f32(n, device):
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------ weights
+class ConvWeights:
+    """bf16 shadow copies of one fp32 OIHW parameter, refreshed when the parameter changes:
+    ``fwd`` [Opad][taps][Ipad] and ``tr`` [Ipad][taps][Opad] (dgrad operand)."""
+
+    def __init__(self, param, k, stride, pad, need_dgrad=True, stem=False):
+        self.param = param
+        self.O, self.I = param.shape[0], param.shape[1]
+        self.k, self.stride, self.pad = k, stride, pad
+        self.stem = stem
+        self.Opad = (self.O + 31) // 32 * 32
+        self.Ipad = 32 if stem else self.I
+        self.need_dgrad = need_dgrad and not stem
+        self.version = -1
+        self.fwd = None
+        self.tr = None
+
+    def refresh(self):
+        p = self.param
+        ver = p._version
+        if self.fwd is not None and ver == self.version and self.fwd.device == p.device:
+            return
+        dev = p.device
+        s = stream_ptr(dev)
+        src = p.detach()
+        so, si, sh, sw = src.stride()
+        if self.stem:
+            if self.fwd is None or self.fwd.device != dev:
+                self.fwd = torch.empty((self.O, 7, 32), dtype=torch.bfloat16, device=dev)
+            check(lib().yv1_prep_stem_weights(ptr(src), so, si, sh, sw, self.O, ptr(self.fwd), s), "yv1_prep_stem_weights")
+        else:
+            taps = self.k * self.k
+            if self.fwd is None or self.fwd.device != dev:
+                self.fwd = torch.empty((self.Opad, taps, self.Ipad), dtype=torch.bfloat16, device=dev)
+                self.tr = torch.empty((self.Ipad, taps, self.Opad), dtype=torch.bfloat16, device=dev) if self.need_dgrad else None
+            check(lib().yv1_prep_weights(ptr(src), so, si, sh, sw, self.O, self.I, self.k, self.k, self.Opad, self.Ipad,
+                                         ptr(self.fwd), ptr(self.tr), s), "yv1_prep_weights")
+        self.version = ver
+
+
+# ------------------------------------------------------------------ convolution
+def conv_out_hw(H, W, k, stride, pad):
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def conv_fwd(x, w, y, want_stats=True):
+    """y = conv(x, w); returns BN-statistic partials [rows][2][Cout_pad] (or None)."""
+    dev = x.t.device
+    M = y.npix
+    stats = None
+    if want_stats:
+        rows = lib().yv1_conv2d_stats_rows(M, w.Opad, w.Ipad)
+        stats = _f32(rows * 2 * w.Opad, dev).view(rows, 2, w.Opad)
+    check(lib().yv1_conv2d_fwd_nhwc_bf16(x.p, ptr(w.fwd), y.p, x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, y.ld, w.k, w.stride,
+                                         w.pad, ptr(stats), stream_ptr(dev)), "yv1_conv2d_fwd_nhwc_bf16")
+    return stats
+
+
+def pack_input(images):
+    """NCHW fp32 -> zero-padded NHWC4 bf16 [N][H+6][W+6][4]."""
+    N, C, H, W = images.shape
+    if C != 3:
+        raise _lib.Yv1Error("the stem expects 3-channel images, got %d" % C)
+    images = images.to(dtype=torch.float32).contiguous()
+    xp = torch.empty((N, H + 6, W + 6, 4), dtype=torch.bfloat16, device=images.device)
+    check(lib().yv1_pack_input_nhwc4(ptr(images), ptr(xp), N, H, W, stream_ptr(images.device)), "yv1_pack_input_nhwc4")
+    return xp
+
+
+def stem_fwd(xp, w, y, H, W):
+    dev = xp.device
+    rows = (y.npix + 127) // 128
+    stats = _f32(rows * 2 * w.O, dev).view(rows, 2, w.O)
+    check(lib().yv1_conv2d_stem_fwd_bf16(ptr(xp), ptr(w.fwd), y.p, y.N, H, W, w.O, y.ld, ptr(stats), stream_ptr(dev)),
+          "yv1_conv2d_stem_fwd_bf16")
+    return stats
+
+
+def conv_dgrad(dy, w, dx, accumulate=False):
+    """dx (+)= conv_transpose(dy, w).  dx has the forward input's geometry."""
+    dev = dy.t.device
+    check(lib().yv1_conv2d_dgrad_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld, w.k,
+                                           w.stride, w.pad, 1 if accumulate else 0, stream_ptr(dev)),
+          "yv1_conv2d_dgrad_nhwc_bf16")
+
+
+def conv_wgrad(x, dy, w):
+    """Returns the fp32 gradient as an OIHW view whose storage is [O][kh][kw][I] (channels_last)."""
+    dev = x.t.device
+    L = lib()
+    taps = w.k * w.k
+    g = torch.empty((w.Opad, taps, w.Ipad), dtype=torch.float32, device=dev)
+    wsb = L.yv1_conv2d_wgrad_workspace_bytes(x.N, dy.H, dy.W, w.Ipad, w.Opad, w.k)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    check(L.yv1_conv2d_wgrad_nhwc_bf16(x.p, dy.p, ptr(g), x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, dy.ld, w.k, w.stride, w.pad,
+                                       ptr(ws), wsb, stream_ptr(dev)), "yv1_conv2d_wgrad_nhwc_bf16")
+    return g[:w.O].view(w.O, w.k, w.k, w.Ipad).permute(0, 3, 1, 2)
+
+
+def stem_wgrad(xp, dy, w, H, W):
+    dev = xp.device
+    L = lib()
+    g = torch.empty((w.O, 7, 32), dtype=torch.float32, device=dev)
+    wsb = L.yv1_conv2d_stem_wgrad_workspace_bytes(dy.N, H, W, w.O)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    check(L.yv1_conv2d_stem_wgrad_bf16(ptr(xp), dy.p, ptr(g), dy.N, H, W, w.O, dy.ld, ptr(ws), wsb, stream_ptr(dev)),
+          "yv1_conv2d_stem_wgrad_bf16")
+    out = torch.empty((w.O, 7, 7, 3), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
+    so, si, sh, sw = out.stride()
+    check(L.yv1_unpack_stem_grad(ptr(g), ptr(out), so, si, sh, sw, w.O, stream_ptr(dev)), "yv1_unpack_stem_grad")
+    return out
+
+
+# ------------------------------------------------------------------ batch norm
+class BNState:
+    """Per-forward state of one BatchNorm: [mean, invstd, scale, shift] rows of one fp32 buffer."""
+    __slots__ = ("buf", "C", "count")
+
+    def __init__(self, C, device):
+        self.buf = torch.empty((4, C), dtype=torch.float32, device=device)
+        self.C = C
+        self.count = 0
+
+    mean = property(lambda s: s.buf[0])
+    invstd = property(lambda s: s.buf[1])
+    scale = property(lambda s: s.buf[2])
+    shift = property(lambda s: s.buf[3])
+
+
+def _shrink_partials(part, rows, W, dev):
+    """Two-stage row reduction when there are many partial rows."""
+    if rows <= 48:
+        return part, rows
+    RB = (rows + 31) // 32
+    r2 = (rows + RB - 1) // RB
+    out = _f32(r2 * W, dev)
+    check(lib().yv1_reduce_rows(ptr(part), ptr(out), rows, W, RB, stream_ptr(dev)), "yv1_reduce_rows")
+    return out, r2
+
+
+def bn_finalize(stats, count, bn, C=None, training=True):
+    """stats [rows][2][ld] partials -> BNState (and running-stat update of module ``bn``)."""
+    dev = stats.device
+    rows, _, ld = stats.shape
+    C = C or bn.num_features
+    st = BNState(C, dev)
+    st.count = count
+    part, rows = _shrink_partials(stats, rows, 2 * ld, dev)
+    check(lib().yv1_bn_finalize(ptr(part), rows, C, ld, float(count), ptr(bn.weight), ptr(bn.bias), BN_EPS, BN_MOMENTUM,
+                                ptr(bn.running_mean) if training else None, ptr(bn.running_var) if training else None,
+                                ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream_ptr(dev)),
+          "yv1_bn_finalize")
+    return st
+
+
+def bn_eval_state(bn):
+    dev = bn.weight.device
+    st = BNState(bn.num_features, dev)
+    check(lib().yv1_bn_eval_coeffs(st.C, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), BN_EPS,
+                                   ptr(st.scale), ptr(st.shift), stream_ptr(dev)), "yv1_bn_eval_coeffs")
+    return st
+
+
+def stats_merge(part, table, c0):
+    """part [rows][2][Cseg] -> table[2][ld] columns [c0, c0+Cseg)."""
+    rows, _, cseg = part.shape
+    dev = part.device
+    part2, rows = _shrink_partials(part, rows, 2 * cseg, dev)
+    check(lib().yv1_stats_merge(ptr(part2), rows, cseg, ptr(table), table.shape[1], c0, stream_ptr(dev)), "yv1_stats_merge")
+
+
+def bn_stats(x):
+    """Stand-alone batch statistics of an activation window -> partials [rows][2][C]."""
+    dev = x.t.device
+    rows = lib().yv1_bn_reduce_rows(x.npix, x.C)
+    part = _f32(rows * 2 * x.C, dev).view(rows, 2, x.C)
+    check(lib().yv1_bn_stats(x.p, x.ld, x.npix, x.C, ptr(part), stream_ptr(dev)), "yv1_bn_stats")
+    return part
+
+
+def bn_apply(y, st, z, relu=True, residual=None, res_state=None):
+    dev = y.t.device
+    check(lib().yv1_bn_apply(y.p, y.ld, z.p, z.ld, residual.p if residual is not None else None,
+                             residual.ld if residual is not None else 0, ptr(st.scale), ptr(st.shift),
+                             ptr(res_state.scale) if res_state is not None else None,
+                             ptr(res_state.shift) if res_state is not None else None, y.npix, y.C, 1 if relu else 0,
+                             stream_ptr(dev)), "yv1_bn_apply")
+
+
+def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=False):
+    """BN (+ReLU) backward.  mask_mode 0: no ReLU; 1: mask from ``z`` > 0; 2: mask from scale*y+shift > 0.
+    Writes dy (grad wrt the raw conv output) and optionally dres (masked dz, the identity-shortcut
+    gradient).  Returns (dgamma, dbeta)."""
+    dev = y.t.device
+    L = lib()
+    C = y.C
+    rows = L.yv1_bn_reduce_rows(y.npix, C)
+    part = _f32(rows * 2 * C, dev)
+    s = stream_ptr(dev)
+    zp, zld = (z.p, z.ld) if z is not None else (None, 0)
+    check(L.yv1_bn_bwd_reduce(dz.p, dz.ld, zp, zld, y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
+                              y.npix, C, mask_mode, ptr(part), s), "yv1_bn_bwd_reduce")
+    part, rows = _shrink_partials(part, rows, 2 * C, dev)
+    gb = torch.empty((5, C), dtype=torch.float32, device=dev)     # dgamma, dbeta, k1, k2, k3
+    check(L.yv1_bn_bwd_finalize(ptr(part), rows, C, float(y.npix), ptr(bn.weight) if bn is not None else None,
+                                ptr(st.invstd), ptr(gb[0]), ptr(gb[1]), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), s),
+          "yv1_bn_bwd_finalize")
+    check(L.yv1_bn_bwd_apply(dz.p, dz.ld, zp, zld, y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
+                             ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), y.npix, C, mask_mode, dy.p, dy.ld,
+                             dres.p if dres is not None else None, dres.ld if dres is not None else 0,
+                             1 if accumulate else 0, s),
+          "yv1_bn_bwd_apply")
+    return gb[0], gb[1]
+
+
+# ------------------------------------------------------------------ pooling / head
+def maxpool_fwd(x, y):
+    check(lib().yv1_maxpool3x3s2_fwd(x.p, x.ld, y.p, y.ld, x.N, x.H, x.W, x.C, stream_ptr(x.t.device)), "yv1_maxpool3x3s2_fwd")
+
+
+def maxpool_bwd(x, dy, dx):
+    check(lib().yv1_maxpool3x3s2_bwd(x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld, x.N, x.H, x.W, x.C, stream_ptr(x.t.device)),
+          "yv1_maxpool3x3s2_bwd")
+
+
+def avgpool_fwd(x, y):
+    check(lib().yv1_avgpool2_fwd(x.p, x.ld, y.p, y.ld, x.N, x.H, x.W, x.C, stream_ptr(x.t.device)), "yv1_avgpool2_fwd")
+
+
+def avgpool_bwd(dy, dx):
+    check(lib().yv1_avgpool2_bwd(dy.p, dy.ld, dx.p, dx.ld, dx.N, dx.H, dx.W, dx.C, stream_ptr(dx.t.device)), "yv1_avgpool2_bwd")
+
+
+def head_fwd(y, st, C):
+    """sigmoid(bn_end(y)) as fp32 [N,H,W,C] (the NHWC tensor the reference gets from permute)."""
+    dev = y.t.device
+    out = torch.empty((y.N, y.H, y.W, C), dtype=torch.float32, device=dev)
+    check(lib().yv1_head_sigmoid_fwd(y.p, y.ld, ptr(st.scale), ptr(st.shift), ptr(out), y.npix, C, stream_ptr(dev)),
+          "yv1_head_sigmoid_fwd")
+    return out
+
+
+def head_bwd(dout, out, y, st, bn, dy):
+    dev = y.t.device
+    C = out.shape[-1]
+    gb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    dout = dout.to(dtype=torch.float32).contiguous()
+    check(lib().yv1_head_sigmoid_bwd(ptr(dout), ptr(out), y.p, y.ld, ptr(bn.weight), ptr(st.mean), ptr(st.invstd), dy.p,
+                                     dy.ld, ptr(gb[0]), ptr(gb[1]), y.npix, C, stream_ptr(dev)), "yv1_head_sigmoid_bwd")
+    return gb[0], gb[1]
