@@ -117,62 +117,78 @@ def init_params(shapes, kind, seed=0):
 # ----------------------------------------------------------------------------
 # functional forward
 # ----------------------------------------------------------------------------
+# ``q`` (optional) is a storage quantiser applied wherever the HIP path stores a tensor in bf16
+# (input image, weights, raw conv outputs, post-activation tensors).  With q=None this is the plain
+# fp32 restatement; with q=bf16_ste the oracle emulates the bf16 storage points so whole-network
+# comparisons are not dominated by rounding noise amplified through ~60 small-batch BatchNorms.
+def bf16_ste(t):
+    """bf16 round-trip with a straight-through gradient."""
+    return t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
+
+
+def _q(t, q):
+    return t if q is None else q(t)
+
+
 def _bn(x, P, name, training, momentum=0.1, eps=1e-5):
     rm, rv = P[name + ".running_mean"], P[name + ".running_var"]
     return F.batch_norm(x, rm, rv, P[name + ".weight"], P[name + ".bias"], training, momentum, eps)
 
 
-def bottleneck(x, P, p, stride, training=True):
+def bottleneck(x, P, p, stride, training=True, q=None):
     """OriginResNet.py:87-107 (stride on the 3x3, :79)."""
-    out = F.relu(_bn(F.conv2d(x, P[p + ".conv1.weight"]), P, p + ".bn1", training))
-    out = F.relu(_bn(F.conv2d(out, P[p + ".conv2.weight"], stride=stride, padding=1), P, p + ".bn2", training))
-    out = _bn(F.conv2d(out, P[p + ".conv3.weight"]), P, p + ".bn3", training)
+    w = lambda k: _q(P[p + k], q)
+    out = _q(F.relu(_bn(_q(F.conv2d(x, w(".conv1.weight")), q), P, p + ".bn1", training)), q)
+    out = _q(F.relu(_bn(_q(F.conv2d(out, w(".conv2.weight"), stride=stride, padding=1), q), P, p + ".bn2", training)), q)
+    out = _bn(_q(F.conv2d(out, w(".conv3.weight")), q), P, p + ".bn3", training)
     if (p + ".downsample.0.weight") in P:
-        idt = _bn(F.conv2d(x, P[p + ".downsample.0.weight"], stride=stride), P, p + ".downsample.1", training)
+        idt = _bn(_q(F.conv2d(x, w(".downsample.0.weight"), stride=stride), q), P, p + ".downsample.1", training)
     else:
         idt = x
-    return F.relu(out + idt)
+    return _q(F.relu(out + idt), q)
 
 
-def resnet50_forward(x, P, S=7, training=True):
+def resnet50_forward(x, P, S=7, training=True, q=None):
     """OriginResNet.py:173-195.  x [N,3,H,W] -> [N,H/64 or H/32, ., B*5+C]."""
-    x = F.relu(_bn(F.conv2d(x, P["conv1.weight"], stride=2, padding=3), P, "bn1", training))
+    x = _q(F.conv2d(_q(x, q), _q(P["conv1.weight"], q), stride=2, padding=3), q)
+    x = _q(F.relu(_bn(x, P, "bn1", training)), q)
     x = F.max_pool2d(x, 3, 2, 1)
     stages = [("layer1", 3, 1), ("layer2", 4, 2), ("layer3", 6, 2), ("layer4", 3, 2)]
     if S == 7:
         stages.append(("layer5", 3, 2))
     for name, blocks, stride in stages:
         for i in range(blocks):
-            x = bottleneck(x, P, "%s.%d" % (name, i), stride if i == 0 else 1, training)
-    x = F.conv2d(x, P["layer6.weight"])
+            x = bottleneck(x, P, "%s.%d" % (name, i), stride if i == 0 else 1, training, q)
+    x = _q(F.conv2d(x, _q(P["layer6.weight"], q)), q)
     x = _bn(x, P, "bn_end", training)
     return torch.sigmoid(x).permute(0, 2, 3, 1)
 
 
-def dense_layer(x, P, p, training=True):
+def dense_layer(x, P, p, training=True, q=None):
     """OriginDenseNet.py:19-36: BN-ReLU-1x1(->128)-BN-ReLU-3x3(->32), cat."""
-    h = F.conv2d(F.relu(_bn(x, P, p + ".norm1", training)), P[p + ".conv1.weight"])
-    h = F.conv2d(F.relu(_bn(h, P, p + ".norm2", training)), P[p + ".conv2.weight"], padding=1)
+    h = _q(F.conv2d(_q(F.relu(_bn(x, P, p + ".norm1", training)), q), _q(P[p + ".conv1.weight"], q)), q)
+    h = _q(F.conv2d(_q(F.relu(_bn(h, P, p + ".norm2", training)), q), _q(P[p + ".conv2.weight"], q), padding=1), q)
     return torch.cat([x, h], 1)
 
 
-def transition(x, P, p, training=True):
+def transition(x, P, p, training=True, q=None):
     """OriginDenseNet.py:47-54."""
-    h = F.conv2d(F.relu(_bn(x, P, p + ".norm", training)), P[p + ".conv.weight"])
-    return F.avg_pool2d(h, 2, 2)
+    h = _q(F.conv2d(_q(F.relu(_bn(x, P, p + ".norm", training)), q), _q(P[p + ".conv.weight"], q)), q)
+    return _q(F.avg_pool2d(h, 2, 2), q)
 
 
-def densenet121_forward(x, P, S=7, training=True):
+def densenet121_forward(x, P, S=7, training=True, q=None):
     """OriginDenseNet.py:114-129."""
-    x = F.relu(_bn(F.conv2d(x, P["features.conv0.weight"], stride=2, padding=3), P, "features.norm0", training))
+    x = _q(F.conv2d(_q(x, q), _q(P["features.conv0.weight"], q), stride=2, padding=3), q)
+    x = _q(F.relu(_bn(x, P, "features.norm0", training)), q)
     x = F.max_pool2d(x, 3, 2, 1)
     cfg = densenet121_block_config(S)
     for bi, nl in enumerate(cfg):
         for li in range(nl):
-            x = dense_layer(x, P, "features.denseblock%d.denselayer%d" % (bi + 1, li + 1), training)
+            x = dense_layer(x, P, "features.denseblock%d.denselayer%d" % (bi + 1, li + 1), training, q)
         if bi != len(cfg) - 1:
-            x = transition(x, P, "features.transition%d" % (bi + 1), training)
-    x = F.relu(_bn(x, P, "features.norm5", training))
-    x = F.conv2d(x, P["layer6.weight"])
+            x = transition(x, P, "features.transition%d" % (bi + 1), training, q)
+    x = _q(F.relu(_bn(x, P, "features.norm5", training)), q)
+    x = _q(F.conv2d(x, _q(P["layer6.weight"], q)), q)
     x = _bn(x, P, "bn_end", training)
     return torch.sigmoid(x).permute(0, 2, 3, 1)
