@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Training-throughput bench for the YOLO-v1 hot path on MI355X (driver contract).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one synthetic batch already resident in HBM:
+forward (ResNet-50, 448x448, S=7) -> YOLOLossV1 -> zero_grad -> backward -> (RCCL gradient
+average, overlapped with backward, when N > 1) -> SGD(momentum 0.99) step, i.e. the loop body
+of the reference's train.py:158-172.  Per-GPU batch is fixed at 64 (weak scaling).
+Rank 0 prints ONE JSON line; ``value`` is whole-job images/sec.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per image, SURVEY.md 8d / BASELINE.md 3 (conv MACs x2, fwd + dgrad + wgrad, stem has no dgrad)
+TRAIN_GFLOP_PER_IMG = {("resnet", 7): 103.25, ("resnet", 14): 97.22, ("densenet", 7): 68.30, ("densenet", 14): 67.09}
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(steps=5, warmup=2):
+    """BASELINE.json configs[0]: ResNet-50 448x448 S=7 batch 2 fp32 on the host cores, through the CPU
+    oracle (our restatement of the reference modules; the reference itself never travels)."""
+    from oracle import train_step as ots
+    torch.set_num_threads(os.cpu_count())
+    P = ots.make_state("resnet", 7, seed=0)
+    images, target = ots.synthetic_batch(2, 7)
+    times = []
+    ots.train_steps(P, images, target, 7, warmup + steps, "resnet", timings=times)
+    t = sorted(times[warmup:])[len(times[warmup:]) // 2]
+    return {"value": round(2.0 / t, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed steps (median) after %d warm-up of batch 2, ResNet-50 448x448 S=7 fp32, "
+                      "oracle port of train.py:158-172" % (steps, warmup)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--backbone", default="resnet", choices=["resnet", "densenet"])
+    ap.add_argument("--S", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-sgd", type=int, default=1)
+    args = ap.parse_args()
+
+    from yolo_v1_amd import distributed as ydist
+    from yolo_v1_amd import _lib
+    from yolo_v1_amd.train import build, learning_rate_policy, train_step
+    from yolo_v1_amd.utils.YOLODataLoader import synthetic_batch
+    _lib.lib()                                   # fail loudly if the HIP library is missing
+    rank, world, device = ydist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+
+    torch.manual_seed(0)
+    net, loss_layer, opt = build(args.backbone, args.S, 2, 20, args.batch, device, quiet=True,
+                                 fused_optimizer=bool(args.fused_sgd))
+    sync = ydist.GradSync(net) if world > 1 else None
+    if world > 1:                                # same initial weights on every rank
+        for p in net.state_dict().values():
+            torch.distributed.broadcast(p, 0)
+    images, target = synthetic_batch(args.batch, args.S, seed=1234 + rank, device=device)
+    lr_map = {1: 0.001, 75: 0.0001, 115: 0.00001}
+
+    lr, it = 0.0, 0
+
+    def step():
+        nonlocal lr, it
+        it += 1
+        lr = learning_rate_policy(it, 0, lr, lr_map)
+        return train_step(net, loss_layer, opt, images, target, lr, sync)
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        loss = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)               # HIP events on the stream every kernel of the step is launched on
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / elapsed
+        gflop = TRAIN_GFLOP_PER_IMG[(args.backbone, args.S)]
+        step_s_dev = dev_ms / 1e3 / args.steps
+        achieved = args.batch * gflop / 1e3 / step_s_dev          # TFLOP/s on one GPU, device time of the step
+        out = {
+            "metric": "images/sec training (ResNet-50 448^2, S=7)" if args.backbone == "resnet" and args.S == 7
+            else "images/sec training (%s 448^2, S=%d)" % (args.backbone, args.S),
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%s 448x448 S=%d B=2 C=20 bf16, per-GPU batch %d, fwd+loss+bwd+SGD(momentum 0.99)%s"
+                                   % ("ResNet-50" if args.backbone == "resnet" else "DenseNet-121", args.S, args.batch,
+                                      "+RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "optimizer": "fused HIP SGD" if args.fused_sgd else "torch.optim.SGD"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "note": "whole training step of one GPU: %.2f algorithmic conv GFLOP/img x %d img / %.3f ms "
+                                 "(HIP-event time of the step on the launch stream)" % (gflop, args.batch, step_s_dev * 1e3)},
+            "final_loss": round(final_loss, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,6 +153,7 @@ class ResNet(HipBackbone):
         grads[self.layer6.weight] = ops.conv_wgrad(x, dyh, wh)
         g = ops.new_act(N, x.H, x.W, x.C, dev)
         ops.conv_dgrad(dyh, wh, g)
+        self._emit(grads, [self.bn_end.weight, self.bn_end.bias, self.layer6.weight])
 
         for (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out) in reversed(rec["blocks"]):
             w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
@@ -184,6 +185,7 @@ class ResNet(HipBackbone):
                 ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate
             else:
                 ops.conv_dgrad(dy1, w1, g_in, accumulate=True)
+            self._emit(grads, list(blk.parameters()))
             g = g_in
 
         xp, y0, s0, z0, H, W = rec["stem"]
@@ -193,6 +195,7 @@ class ResNet(HipBackbone):
         dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
         grads[self.bn1.weight], grads[self.bn1.bias] = ops.bn_backward(dz0, y0, s0, self.bn1, dy0, 2)
         grads[self.conv1.weight] = ops.stem_wgrad(xp, dy0, w0, H, W)
+        self._emit(grads, [self.bn1.weight, self.bn1.bias, self.conv1.weight])
         return grads
 
 

@@ -71,6 +71,17 @@ class HipBackbone(nn.Module):
     def __init__(self):
         super().__init__()
         self._convw = {}      # ConvParam -> ops.ConvWeights
+        self._grad_ready_hook = None
+
+    def set_grad_ready_hook(self, fn):
+        """``fn([(param, grad), ...])`` is called from inside the backward executor as soon as the
+        kernels producing those parameter gradients have been launched (used by distributed.GradSync
+        to overlap the all-reduce with the rest of the backward)."""
+        self._grad_ready_hook = fn
+
+    def _emit(self, grads, params):
+        if self._grad_ready_hook is not None:
+            self._grad_ready_hook([(p, grads[p]) for p in params if p in grads])
 
     def cw(self, conv, **kw):
         w = self._convw.get(conv)

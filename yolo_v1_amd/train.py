@@ -1,0 +1,128 @@
+"""Training entry point with the reference's train.py surface (train.py:22-209), MI355X-native.
+
+The reference's file is module-level code that no longer parses (unresolved merge conflicts at
+:49-53, :136-141, :193-197); this module reproduces its behaviour as functions:
+  * ``warmming_up_policy`` / ``learning_rate_policy``       train.py:22-32
+  * ``build`` (backbone, loss layer, SGD momentum 0.99)     train.py:56-101
+  * ``train_step`` = the loop body                          train.py:157-172
+  * ``main`` = the epoch loop with its log line format      train.py:144-184
+One process per GPU; with WORLD_SIZE > 1 the gradients are averaged over RCCL by
+``yolo_v1_amd.distributed.GradSync`` while the backward is still running.
+Evaluation (train.py:187-198) lives in ``yolo_v1_amd.eval``.
+"""
+import argparse
+import os
+import time
+
+import torch
+
+from .v1Loss import YOLOLossV1
+
+# defaults of the reference's module-level constants (train.py:34-57); the merge conflict at :49-53
+# leaves two candidates for the last LR drop, 115 (HEAD) is taken
+DEFAULTS = dict(learning_rate=0.0, num_epochs=200, batch_size=12, B=2, S=14, clsN=20, lbd_coord=5., lbd_no_obj=.5,
+                lr_adjust_map={1: 0.001, 75: 0.0001, 115: 0.00001}, backbone='densenet')
+
+
+def warmming_up_policy(now_iter, now_lr, stop_down_iter=1000):
+    if now_iter <= stop_down_iter:
+        now_lr += 0.000001
+    return now_lr
+
+
+def learning_rate_policy(now_iter, now_epoch, now_lr, lr_adjust_map, stop_down_iter=1000):
+    now_lr = warmming_up_policy(now_iter, now_lr, stop_down_iter)
+    if now_epoch in lr_adjust_map.keys():
+        now_lr = lr_adjust_map[now_epoch]
+    return now_lr
+
+
+def build(backbone='resnet', S=7, B=2, clsN=20, batch_size=16, device='cuda:0', lbd_coord=5., lbd_no_obj=.5,
+          logger=None, vis=None, quiet=False, with_sgd=True, fused_optimizer=False):
+    """Backbone + loss layer + optimizer as train.py:56-101 sets them up (no pretrained download:
+    that needs the network, train.py:61/:72)."""
+    if backbone == 'resnet':
+        from .backbones.OriginResNet import resnet50
+        net = resnet50(S=S).to(device)
+    else:
+        from .backbones.OriginDenseNet import densenet121
+        net = densenet121(S=S).to(device)
+    net.train()
+    if with_sgd:
+        if fused_optimizer:
+            from .optim import FusedSGD
+            opt = FusedSGD(net.parameters(), lr=0.0, momentum=0.99)
+        else:
+            opt = torch.optim.SGD(net.parameters(), lr=0.0, momentum=0.99)          # train.py:84
+    else:
+        opt = torch.optim.Adam(net.parameters(), lr=0.0, weight_decay=1e-8)         # train.py:88
+    loss_layer = YOLOLossV1(batch_size, S, B, clsN, lbd_coord, lbd_no_obj, _device=device, _logger=logger, _vis=vis,
+                            _quiet=quiet)
+    return net, loss_layer, opt
+
+
+def train_step(net, loss_layer, optimizer, images, target, lr, grad_sync=None):
+    """One iteration of train.py:158-172: set LR, forward, loss, zero_grad, backward, step.
+    Returns the loss as a 0-dim device tensor (no host sync)."""
+    for param_group in optimizer.param_groups:
+        param_group['lr'] = lr
+    pred = net(images)
+    loss = loss_layer(pred, target)
+    optimizer.zero_grad()
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync.finish()
+    optimizer.step()
+    return loss
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="YOLO-v1 training on MI355X (reference train.py surface)")
+    ap.add_argument("--backbone", default=DEFAULTS["backbone"], choices=["densenet", "resnet"])
+    ap.add_argument("--S", type=int, default=DEFAULTS["S"])
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--epochs", type=int, default=DEFAULTS["num_epochs"])
+    ap.add_argument("--iters-per-epoch", type=int, default=20, help="synthetic data: iterations per epoch")
+    ap.add_argument("--save-dir", default=None)
+    args = ap.parse_args(argv)
+    from . import distributed as ydist
+    from .utils.YOLODataLoader import synthetic_batch
+    from .utils.utils import create_logger
+    rank, world, device = ydist.init_from_env()
+    bs = args.batch_size or (16 if args.backbone == 'resnet' else DEFAULTS["batch_size"])      # train.py:68
+    opt_name = 'sgd'
+    base = args.save_dir or '%s_%s_cellSize%d/' % (args.backbone, opt_name, args.S)              # train.py:91
+    logger = create_logger(base, 'train') if rank == 0 else None
+    net, loss_layer, opt = build(args.backbone, args.S, DEFAULTS["B"], DEFAULTS["clsN"], bs, device, logger=logger,
+                                 quiet=rank != 0)
+    sync = ydist.GradSync(net) if world > 1 else None
+    images, target = synthetic_batch(bs, args.S, seed=1234 + rank, device=device)
+    lr, it = DEFAULTS["learning_rate"], 0
+    for epoch in range(args.epochs):
+        if logger:
+            logger.info('\n\nStarting epoch %d / %d' % (epoch + 1, args.epochs))
+            logger.info('Learning Rate for this epoch: {}'.format(opt.param_groups[0]['lr']))
+        total_loss, t_epoch = 0., time.perf_counter()
+        for i in range(args.iters_per_epoch):
+            t0 = time.perf_counter()
+            it += 1
+            lr = learning_rate_policy(it, epoch, lr, DEFAULTS["lr_adjust_map"])
+            loss = train_step(net, loss_layer, opt, images, target, lr, sync)
+            total_loss += loss.item()                                                            # train.py:168
+            dt = time.perf_counter() - t0
+            if (i + 1) % 5 == 0 and logger:
+                logger.info('Epoch [%d/%d], Iter [%d/%d] expect end in %.2f min. Loss: %.4f, average_loss: %.4f, '
+                            'now learning rate: %f' % (epoch + 1, args.epochs, i + 1, args.iters_per_epoch,
+                                                       dt * (args.iters_per_epoch - i + 1) // 60, loss.item(),
+                                                       total_loss / (i + 1), lr))               # train.py:177
+        if logger:
+            logger.info('Epoch {} / {} finished, cost time {:.2f} min.'.format(epoch, args.epochs,
+                                                                              (time.perf_counter() - t_epoch) / 60))
+        if rank == 0:
+            os.makedirs(base, exist_ok=True)
+            sd = {'module.' + k: v for k, v in net.state_dict().items()}    # nn.DataParallel key prefix (train.py:80,:209)
+            torch.save(sd, '%s/%s_%s_S%d_yolo.pth' % (base, args.backbone, opt_name, args.S))
+
+
+if __name__ == "__main__":
+    main()

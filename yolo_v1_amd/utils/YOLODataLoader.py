@@ -1,0 +1,121 @@
+"""Drop-in for the reference's ``utils/YOLODataLoader.py`` surface that the hot path needs.
+
+``yoloDataset`` keeps the constructor signature and the ``__getitem__`` tuple
+(``img[3,448,448], target[S,S,B*5+C][, fname]``, reference :13, :156-194) and the target
+``encoder`` (:200-230).  Two sources:
+  * ``list_file=None`` (or ``synthetic=True``): VOC-shaped synthetic samples -- images
+    ``randn(3,448,448)``, ``objs`` boxes with cx,cy~U(0,1), w,h~U(0.05,0.9), class~U{0..C-1}
+    (SURVEY 8d); nothing is read from disk, so the throughput bench needs no dataset;
+  * a darknet-style label list (``<img path>`` lines, labels next to the images as
+    ``cls cx cy w h`` rows, reference :94-106): boxes/labels are read and encoded; image decoding
+    and the imgaug pipeline (:31-79, :161-172) need cv2/imgaug and are out of scope here, so an
+    ``image_loader`` callable must be supplied for real images.
+The encoder is host code, as in the reference (it runs in DataLoader worker processes).
+"""
+import math
+
+import torch
+import torch.utils.data as data
+
+
+def encode_boxes(boxes, labels, S, B=2, C=20):
+    """[k,4] normalised (cx,cy,w,h) + [k] labels -> target [S,S,B*5+C] (reference :200-230).
+
+    Cell = ceil(c / (1/S)) - 1 per axis (row = y, col = x); a later box landing in an occupied cell
+    replaces it; both confidence slots are 1; the box (offset inside the cell, w, h) fills every
+    slot; one-hot class.
+    """
+    D = B * 5 + C
+    target = torch.zeros((S, S, D))
+    boxes = torch.as_tensor(boxes, dtype=torch.float32).reshape(-1, 4)
+    if boxes.shape[0] == 0:
+        return target
+    cell = torch.tensor(1.0 / S, dtype=torch.float32)
+    ij = torch.ceil(boxes[:, :2] / cell) - 1            # [k,2] (col, row)
+    delta = (boxes[:, :2] - ij * cell) / cell
+    for k in range(boxes.shape[0]):
+        col, row = int(ij[k, 0]), int(ij[k, 1])
+        cellv = torch.zeros(D)
+        cellv[:B] = 1
+        cellv[B * 5 + int(labels[k])] = 1
+        cellv[B:B * 5] = torch.cat([delta[k], boxes[k, 2:]]).repeat(B)
+        target[row, col] = cellv
+    return target
+
+
+class yoloDataset(data.Dataset):
+    image_size = 448
+
+    def __init__(self, list_file=None, train=True, transform=None, device='cpu', little_train=False,
+                 with_file_path=False, S=7, B=2, C=20, test_mode=False, synthetic=None, length=512, objs=3,
+                 seed=1234, image_loader=None):
+        self.train = train
+        self.transform = transform
+        self.S, self.B, self.C = S, B, C
+        self.device = device
+        self.with_file_path = with_file_path
+        self._test = test_mode
+        self.synthetic = (list_file is None) if synthetic is None else synthetic
+        self.objs = objs
+        self.seed = seed
+        self.image_loader = image_loader
+        self.fnames = []
+        if not self.synthetic:
+            with open(list_file) as f:
+                lines = f.readlines()
+            if little_train:
+                lines = lines[:64 * 8]
+            self.fnames = [ln.strip().split()[0] for ln in lines if ln.strip()]
+            self.num_samples = len(self.fnames)
+        else:
+            self.num_samples = length
+
+    def __len__(self):
+        return self.num_samples
+
+    def encoder(self, boxes, labels):
+        return encode_boxes(boxes, labels, self.S, self.B, self.C)
+
+    @staticmethod
+    def get_boxes_labels(in_path):
+        boxes, labels = [], []
+        with open(in_path.replace('JPEGImages', 'labels').replace('jpg', 'txt'), 'r') as f:
+            for line in f:
+                ll = line.strip().split(' ')
+                labels.append(int(ll[0]))
+                boxes.append([float(v) for v in ll[1:5]])
+        return torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4), torch.tensor(labels, dtype=torch.long)
+
+    def _synthetic_item(self, idx):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
+        img = torch.randn(3, self.image_size, self.image_size, generator=g)
+        cxcy = torch.rand(self.objs, 2, generator=g).clamp_(1e-3, 1.0)
+        wh = torch.rand(self.objs, 2, generator=g) * 0.85 + 0.05
+        labels = torch.randint(0, self.C, (self.objs,), generator=g)
+        return img, torch.cat([cxcy, wh], 1), labels, "synthetic_%06d.jpg" % idx
+
+    def __getitem__(self, idx):
+        if self.synthetic:
+            img, boxes, labels, fname = self._synthetic_item(idx)
+        else:
+            fname = self.fnames[idx]
+            if self.image_loader is None:
+                raise RuntimeError("yoloDataset: reading real images needs an image_loader callable "
+                                   "(cv2/imgaug are not part of this package)")
+            img = self.image_loader(fname)
+            if self.transform is not None:
+                img = self.transform(img)
+            boxes, labels = self.get_boxes_labels(fname)
+        target = self.encoder(boxes, labels)
+        if self.with_file_path:
+            return img, target, fname
+        return img, target
+
+
+def synthetic_batch(N, S, B=2, C=20, seed=1234, objs=3, hw=448, device='cpu'):
+    """A whole synthetic batch (images [N,3,hw,hw] fp32, targets [N,S,S,B*5+C]) for benches/smoke."""
+    ds = yoloDataset(None, S=S, B=B, C=C, objs=objs, seed=seed, length=N)
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(N, 3, hw, hw, generator=g)
+    targets = torch.stack([ds.encoder(*ds._synthetic_item(i)[1:3]) for i in range(N)])
+    return images.to(device), targets.to(device)
