@@ -1,0 +1,128 @@
+/* yv1.h -- C ABI of libyv1.so, the MI355X (gfx950) hot path of YOLO-v1 training.
+ *
+ * The reference (haoran1062/YOLO_V1) is pure Python on PyTorch: it has no FFI of its own.  Each
+ * entry point below replaces the ATen/cuDNN work behind a reference call site (cited per group);
+ * the Python binding a maintainer adds is the ctypes table in yolo_v1_amd/_lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors in the host layer);
+ *     outputs and workspaces are caller-allocated; nothing is allocated or freed inside;
+ *   - `stream` is the hipStream_t (passed as void*) all work is enqueued on; calls are asynchronous;
+ *   - return value: 0 on success, a hipError_t value, or YV1_ERR_* below;
+ *   - activations: NHWC bfloat16; `ld*` = pixel stride in elements (>= channels, multiple of 8), so a
+ *     channel window of a wider buffer is addressed by offsetting the base pointer;
+ *   - "stats partials": fp32 [rows][2][C] = per-tile (sum, sum of squares) rows to be summed.
+ */
+#ifndef YV1_H
+#define YV1_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YV1_ERR_BAD_ARG 1001
+#define YV1_ERR_UNSUPPORTED 1002
+#define YV1_ERR_WORKSPACE 1003
+
+typedef void* yv1_stream_t; /* hipStream_t */
+
+/* ---- loss: v1Loss.py:22-118 (YOLOLossV1.forward) + its autograd backward; utils/utils.py:10-75 --------- */
+size_t yv1_loss_workspace_bytes(int N, int S);
+/* pred [N,S,S,B*5+C] fp32 with element strides ps0..ps3 (the reference passes a permuted NCHW view,
+ * OriginResNet.py:189); target contiguous.  Writes the total (v1Loss.py:104-105, divided by batch_size),
+ * the 4 raw component sums {location, contain, not-contain, classify} (v1Loss.py:108) and, when grad_pred
+ * != NULL, d total / d pred (contiguous), including the gradient through the IoU target. */
+int yv1_loss_fwd_bwd(const float* pred, long long ps0, long long ps1, long long ps2, long long ps3, const float* target,
+                     int N, int S, int B, int C, float l_coord, float l_noobj, float batch_size, float* out_loss,
+                     float* out_components, float* grad_pred, void* workspace, size_t workspace_bytes,
+                     yv1_stream_t stream);
+/* x[i] *= *scalar (device scalar): chains the upstream autograd gradient without a host sync */
+int yv1_scale_by_device_scalar(float* x, const float* scalar, long long n, yv1_stream_t stream);
+
+/* ---- decoder + NMS: utils/utils.py:94-147 (decoder), :150-184 (nms), :10-57, :59-75 ------------------ */
+/* One workgroup per image.  pred [N,S,S,B*5+C] fp32 contiguous.  Outputs are [N][S*S*B] rows valid up to
+ * out_counts[n]: boxes (x1,y1,x2,y2), class index (int64), score, candidate index (int64, position in the
+ * (row,col,box)-ordered candidate list) in keep order; out_ncand[n] = candidates before NMS (0 means the
+ * reference's single all-zero box was substituted, utils.py:134-137).  thresh is compared in double. */
+int yv1_decode_nms_batched(const float* pred, int N, int S, int B, int C, double thresh, float nms_th, float* out_boxes,
+                           long long* out_cls, float* out_scores, long long* out_keep_idx, int* out_counts,
+                           int* out_ncand, yv1_stream_t stream);
+/* greedy class-agnostic NMS, n <= 896; out_keep: indices into the input in keep order */
+int yv1_nms(const float* boxes, const float* scores, int n, float threshold, long long* out_keep, int* out_count,
+            yv1_stream_t stream);
+int yv1_iou_matrix(const float* b1, int n, const float* b2, int m, float* out, yv1_stream_t stream);
+int yv1_convert_cxcywh_to_xyxy(const float* in, int n, int S, float* out, yv1_stream_t stream);
+
+/* ---- convolution: nn.Conv2d behind OriginResNet.py:21-29,:121,:159-163; OriginDenseNet.py:24-29,:52-53,:77,:101 */
+/* y = conv(x, w), square kernel k; w bf16 [Cout][k*k][Cin] (Cin % 32 == 0, Cout % 32 == 0).
+ * stats (nullable): BatchNorm partials [yv1_conv2d_stats_rows(M,Cout,Cin)][2][Cout], M = N*OH*OW. */
+int yv1_conv2d_fwd_nhwc_bf16(const void* x, const void* w, void* y, int N, int IH, int IW, int ldx, int Cin, int Cout,
+                             int ldy, int k, int stride, int pad, float* stats, yv1_stream_t stream);
+int yv1_conv2d_stats_rows(int M, int Cout, int Cin);
+/* 7x7/2 pad-3 stem over the packed image: xp [N][H+6][W+6][4] bf16; w bf16 [Cout][7][32] */
+int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy, float* stats,
+                             yv1_stream_t stream);
+int yv1_pack_input_nhwc4(const float* x_nchw, void* y, int N, int H, int W, yv1_stream_t stream);
+/* dx (+)= conv_transpose(dy, w); wt bf16 [Cin][k*k][Cout]; stride 1 or 2.  1x1 strided: only the sampled
+ * pixels of dx are written (accumulate into a dx the main path already wrote). */
+int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin, int Cout,
+                               int lddy, int k, int stride, int pad, int accumulate, yv1_stream_t stream);
+/* dw fp32 [Cout][k*k][Cin] (= channels_last storage of the OIHW gradient) */
+size_t yv1_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int k);
+int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx, int Cin, int Cout,
+                               int lddy, int k, int stride, int pad, void* workspace, size_t workspace_bytes,
+                               yv1_stream_t stream);
+size_t yv1_conv2d_stem_wgrad_workspace_bytes(int N, int H, int W, int Cout);
+int yv1_conv2d_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int N, int H, int W, int Cout, int lddy,
+                               void* workspace, size_t workspace_bytes, yv1_stream_t stream);
+
+/* ---- BatchNorm (train mode), ReLU, residual add: OriginResNet.py:90-105,:174-177,:187; OriginDenseNet.py:22-27 */
+int yv1_reduce_rows(const float* in, float* out, int rows, int W, int RB, yv1_stream_t stream);
+int yv1_stats_merge(const float* partials, int rows, int Cseg, float* table, int ldo, int c0, yv1_stream_t stream);
+int yv1_bn_finalize(const float* partials, int rows, int C, int ld_partials, float count, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                    float* invstd, float* scale, float* shift, yv1_stream_t stream);
+int yv1_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* scale, float* shift, yv1_stream_t stream);
+/* z = relu?(scale*y + shift [+ residual | + res_scale*residual + res_shift]) */
+int yv1_bn_apply(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
+                 const float* shift, const float* res_scale, const float* res_shift, long long npix, int C, int relu,
+                 yv1_stream_t stream);
+int yv1_bn_reduce_rows(long long npix, int C);
+int yv1_bn_stats(const void* y, int ldy, long long npix, int C, float* partials, yv1_stream_t stream);
+/* mask_mode: 0 none, 1 ReLU mask from z > 0, 2 ReLU mask from scale*y+shift > 0 */
+int yv1_bn_bwd_reduce(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                      const float* invstd, const float* scale, const float* shift, long long npix, int C, int mask_mode,
+                      float* partials, yv1_stream_t stream);
+int yv1_bn_bwd_finalize(const float* partials, int rows, int C, float count, const float* gamma, const float* invstd,
+                        float* dgamma, float* dbeta, float* k1, float* k2, float* k3, yv1_stream_t stream);
+int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                     const float* invstd, const float* scale, const float* shift, const float* k1, const float* k2,
+                     const float* k3, long long npix, int C, int mask_mode, void* dy, int lddy, void* dres, int lddres,
+                     int accumulate, yv1_stream_t stream);
+
+/* ---- pooling and head: OriginResNet.py:125,:188-189; OriginDenseNet.py:54,:80,:127-128 --------------------- */
+int yv1_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, yv1_stream_t stream);
+int yv1_maxpool3x3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C,
+                         yv1_stream_t stream);
+int yv1_avgpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, yv1_stream_t stream);
+int yv1_avgpool2_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, yv1_stream_t stream);
+int yv1_head_sigmoid_fwd(const void* y, int ldy, const float* scale, const float* shift, float* out, long long npix,
+                         int C, yv1_stream_t stream);
+int yv1_head_sigmoid_bwd(const float* dout, const float* out, const void* y, int ldy, const float* gamma, const float* mean,
+                         const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, long long npix, int C,
+                         yv1_stream_t stream);
+
+/* ---- weight re-layout (fp32 OIHW parameter, any strides -> bf16 kernel layouts) ------------------------------ */
+int yv1_prep_weights(const float* w, long long so, long long si, long long sh, long long sw, int O, int I, int KH, int KW,
+                     int Opad, int Ipad, void* dst_fwd, void* dst_t, yv1_stream_t stream);
+int yv1_prep_stem_weights(const float* w, long long so, long long si, long long sh, long long sw, int O, void* dst,
+                          yv1_stream_t stream);
+int yv1_unpack_stem_grad(const float* g, float* dw, long long so, long long si, long long sh, long long sw, int O,
+                         yv1_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YV1_H */

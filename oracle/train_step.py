@@ -107,5 +107,5 @@ def train_steps(P, images, target, S, steps, kind="resnet", B=2, C=20, batch_siz
         opt.step(lr)
         if timings is not None:
             timings.append(time.perf_counter() - t0)
-        out.append({"loss": float(total), "comps": [float(c) for c in comps], "lr": lr})
+        out.append({"loss": float(total.detach()), "comps": [float(c.detach()) for c in comps], "lr": lr})
     return out

@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library loads and exports every symbol include/yv1.h declares (no compute calls),
+and the ctypes table in yolo_v1_amd/_lib.py lists exactly those symbols."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "yv1.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(yv1_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_matches_ctypes_table_and_library_exports():
+    from yolo_v1_amd import _lib, build
+    syms = _header_symbols()
+    assert len(syms) >= 30
+    assert syms == sorted(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)          # hipcc cross-compiles without a GPU
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(L, s), "libyv1.so does not export " + s
+    # argument-count sanity against the header prototypes
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "yv1.h")).read(), flags=re.S)
+    for s in syms:
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % s, txt, flags=re.S)
+        nargs = len([a for a in m.group(1).split(",") if a.strip()])
+        assert nargs == len(_lib.SIGNATURES[s][1]), s
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import pytest
+    from yolo_v1_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libyv1.so")
+    with pytest.raises(_lib.Yv1Error):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under yolo_v1_amd/ may import it
+    bad = []
+    for dp, _, fns in os.walk(os.path.join(ROOT, "yolo_v1_amd")):
+        for fn in fns:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dp, fn)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    import pytest
+    import torch
+    from yolo_v1_amd import _lib
+    from yolo_v1_amd.utils import utils as yu
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    with pytest.raises(_lib.Yv1Error):
+        yu.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+    with pytest.raises(_lib.Yv1Error):
+        YOLOLossV1(1, 7, 2, 20, _quiet=True)(torch.zeros(1, 7, 7, 30), torch.zeros(1, 7, 7, 30))

@@ -1,0 +1,200 @@
+"""GPU parity of the DenseNet-121 backbone (HIP, bf16, concat-free block buffers) against the CPU
+oracle (fp32 math with bf16-storage emulation), forward, backward and eval mode.  Tolerances as in
+test_gpu_resnet.py; the kernels themselves are pinned element-wise in test_gpu_ops.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("S,N,hw", [(7, 4, 192), (14, 4, 128)])
+def test_densenet121_forward_backward_vs_oracle(S, N, hw):
+    from oracle import backbones as ob
+    from yolo_v1_amd.backbones.OriginDenseNet import densenet121
+    P = ob.init_params(ob.densenet121_param_shapes(S), "densenet", seed=5)
+    net = densenet121(S=S)
+    net.load_state_dict(P, strict=True)
+    net = net.to(DEV).train()
+    x = torch.randn(N, 3, hw, hw, generator=torch.Generator().manual_seed(2))
+    for k, v in P.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    ref = ob.densenet121_forward(x, P, S, training=True, q=ob.bf16_ste)
+    gup = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3)) * 0.1
+    ref.backward(gup)
+    pred = net(x.to(DEV))
+    grid = hw // (64 if S == 7 else 32)
+    assert tuple(pred.shape) == (N, grid, grid, 30)
+    d = (pred.detach().cpu() - ref.detach()).abs()
+    # 121 bf16 layers, no residual damping, BatchNorm over <= 36 samples in the last block: measured mean 2.3e-2,
+    # max 1.2e-1 with every layer within 4e-3 rel of fp32 math when teacher-forced (test below)
+    assert d.max().item() <= 2e-1 and d.mean().item() <= 4e-2, "max %g mean %g" % (d.max().item(), d.mean().item())
+    pred.backward(gup.to(DEV))
+    sd = dict(net.named_parameters())
+    bad = []
+    for k, v in P.items():
+        if not v.requires_grad:
+            continue
+        gg = sd[k].grad
+        assert gg is not None and tuple(gg.shape) == tuple(v.shape), k
+        c = _cos(gg.cpu(), v.grad)
+        ratio = float(gg.norm().cpu() / (v.grad.norm() + 1e-30))
+        # 121 bf16 layers of discontinuous ReLU / max-pool routing between two noisy forwards: a sanity bound only
+        # (measured: 0.70 at conv0 .. 0.98 at the head).  The stem BatchNorm's gamma gradient is the sum over the
+        # max-pool argmax positions and moves with every near-tie, so only its direction is checked loosely; the
+        # same chain is pinned on identical inputs in test_gpu_ops.py::test_stem_chain_backward.
+        if k.startswith("features.norm0"):
+            if c < 0.3:
+                bad.append((k, round(c, 4), round(ratio, 3)))
+        elif not (c >= 0.50 and 0.8 <= ratio <= 1.25):
+            bad.append((k, round(c, 4), round(ratio, 3)))
+    assert not bad, bad[:10]
+    got = net.state_dict()
+    np.testing.assert_allclose(got["features.denseblock2.denselayer3.norm1.running_mean"].cpu().numpy(),
+                               P["features.denseblock2.denselayer3.norm1.running_mean"].numpy(), rtol=3e-2, atol=3e-3)
+    assert int(got["features.norm5.num_batches_tracked"]) == 1
+
+
+def test_densenet121_eval_mode_and_train_steps():
+    from oracle import backbones as ob
+    from yolo_v1_amd.backbones.OriginDenseNet import densenet121
+    from yolo_v1_amd.utils.YOLODataLoader import synthetic_batch
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    S = 14
+    P = ob.init_params(ob.densenet121_param_shapes(S), "densenet", seed=6)
+    for k in P:
+        if k.endswith("running_var"):
+            P[k] = P[k] * 1.3 + 0.1
+    net = densenet121(S=S)
+    net.load_state_dict(P)
+    net = net.to(DEV).eval()
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        a = net(x.to(DEV)).cpu()
+        ref = ob.densenet121_forward(x, P, S, training=False, q=ob.bf16_ste)
+    assert (a - ref).abs().max().item() <= 3e-2
+    net.train()
+    images, target = synthetic_batch(8, 4, hw=128, device=DEV)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
+    crit = YOLOLossV1(8, 4, 2, 20, _quiet=True)
+    losses = []
+    for _ in range(10):
+        loss = crit(net(images), target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_densenet121_every_layer_teacher_forced():
+    """Every tensor the HIP forward produces against fp32 torch math applied to the HIP path's own (bf16)
+    input of that layer -- includes the in-place channel-slice writes that replace torch.cat and the
+    statistics table that replaces per-BatchNorm statistic passes."""
+    import torch.nn.functional as F
+    from oracle import backbones as ob
+    from yolo_v1_amd.backbones.OriginDenseNet import densenet121
+    S, N, hw = 7, 4, 192
+    P = ob.init_params(ob.densenet121_param_shapes(S), "densenet", seed=5)
+    net = densenet121(S=S)
+    net.load_state_dict(P)
+    net = net.to(DEV).train()
+    x = torch.randn(N, 3, hw, hw, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        pred, rec = net._run_forward(x.to(DEV), True, True)
+    torch.cuda.synchronize()
+    bfw = lambda k: P[k].to(torch.bfloat16).float()
+
+    def nchw(a, c0=0, C=None):
+        t = a.t.float().cpu()
+        C = C if C is not None else a.C
+        return t[..., a.c0 + c0: a.c0 + c0 + C].permute(0, 3, 1, 2).contiguous()
+
+    def chk(name, got, want):
+        rel = float((got - want).abs().max() / (want.abs().max() + 1e-9))
+        assert rel <= 1e-2, "%s: rel err %.3g" % (name, rel)
+
+    bnf = lambda t, k: F.batch_norm(t, None, None, P[k + ".weight"], P[k + ".bias"], True)
+    xp, y0, s0, z0, H, W = rec["stem"]
+    chk("stem conv", nchw(y0), F.conv2d(x.to(torch.bfloat16).float(), bfw("features.conv0.weight"), stride=2, padding=3))
+    chk("stem bn", nchw(z0), F.relu(bnf(nchw(y0), "features.norm0")))
+    bi, prev_yc = 0, None
+    for st in rec["stages"]:
+        if st[0] == "block":
+            bi += 1
+            _, buf, lrecs, nf = st
+            first = nchw(buf, 0, nf)
+            chk("pool into block %d" % bi, first, F.max_pool2d(nchw(z0), 3, 2, 1) if bi == 1 else F.avg_pool2d(prev_yc, 2, 2))
+            for li, (layer, cin, st1, t1, y1, st2, t2) in enumerate(lrecs):
+                p = "features.denseblock%d.denselayer%d" % (bi, li + 1)
+                chk(p + " t1", nchw(t1), F.relu(bnf(nchw(buf, 0, cin), p + ".norm1")))
+                chk(p + " y1", nchw(y1), F.conv2d(nchw(t1), bfw(p + ".conv1.weight")))
+                chk(p + " t2", nchw(t2), F.relu(bnf(nchw(y1), p + ".norm2")))
+                chk(p + " slice", nchw(buf, cin, 32), F.conv2d(nchw(t2), bfw(p + ".conv2.weight"), padding=1))
+        else:
+            _, tr, buf, stt, t, yc = st
+            p = "features.transition%d" % bi
+            chk(p + " t", nchw(t), F.relu(bnf(nchw(buf), p + ".norm")))
+            chk(p + " yc", nchw(yc), F.conv2d(nchw(t), bfw(p + ".conv.weight")))
+            prev_yc = nchw(yc)
+    buf, st5, t5, yh, sh, pr = rec["head"]
+    chk("norm5", nchw(t5), F.relu(bnf(nchw(buf), "features.norm5")))
+    chk("head conv", nchw(yh, 0, 30), F.conv2d(nchw(t5), bfw("layer6.weight")))
+    ref = torch.sigmoid(bnf(nchw(yh, 0, 30), "bn_end")).permute(0, 2, 3, 1)
+    assert float((pr.cpu() - ref).abs().max()) <= 2e-3
+
+
+def test_mini_densenet_backward_tight():
+    """A 2-block DenseNet (same executor, 4 dense layers + 1 transition) is shallow enough that bf16 noise
+    does not swamp the comparison: gradients of every parameter against fp32 autograd, cosine >= 0.99."""
+    import torch.nn.functional as F
+    from oracle import backbones as ob
+    from yolo_v1_amd.backbones.OriginDenseNet import DenseNet
+    torch.manual_seed(0)
+    net = DenseNet(block_config=(2, 2), S=14)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+    P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
+    for k, v in P.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    net = net.to(DEV).train()
+    N, hw = 6, 64
+    x = torch.randn(N, 3, hw, hw, generator=torch.Generator().manual_seed(9))
+    q = ob.bf16_ste
+    h = q(F.conv2d(q(x), q(P["features.conv0.weight"]), stride=2, padding=3))
+    h = q(F.relu(ob._bn(h, P, "features.norm0", True)))
+    h = F.max_pool2d(h, 3, 2, 1)
+    for li in (1, 2):
+        h = ob.dense_layer(h, P, "features.denseblock1.denselayer%d" % li, True, q)
+    h = ob.transition(h, P, "features.transition1", True, q)
+    for li in (1, 2):
+        h = ob.dense_layer(h, P, "features.denseblock2.denselayer%d" % li, True, q)
+    h = q(F.relu(ob._bn(h, P, "features.norm5", True)))
+    h = q(F.conv2d(h, q(P["layer6.weight"])))
+    ref = torch.sigmoid(ob._bn(h, P, "bn_end", True)).permute(0, 2, 3, 1)
+    gup = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+    ref.backward(gup)
+    pred = net(x.to(DEV))
+    assert (pred.detach().cpu() - ref.detach()).abs().max().item() <= 2e-2
+    pred.backward(gup.to(DEV))
+    bad = []
+    for k, p in net.named_parameters():
+        c = _cos(p.grad.cpu(), P[k].grad)
+        ratio = float(p.grad.norm().cpu() / (P[k].grad.norm() + 1e-30))
+        if k.startswith("features.norm0"):        # see the note in the full-size test
+            ok = c >= 0.5
+        else:
+            ok = c >= 0.97 and 0.92 <= ratio <= 1.08
+        if not ok:
+            bad.append((k, round(c, 4), round(ratio, 3)))
+    assert not bad, bad

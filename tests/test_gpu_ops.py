@@ -235,3 +235,48 @@ def test_head_fwd_bwd():
     assert not got[:, C:].any()
     np.testing.assert_allclose(dg.cpu().numpy(), ref_bn.weight.grad.numpy(), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_stem_chain_backward():
+    """conv7x7/2 -> BN -> ReLU -> maxpool forward, then backward from a pooled-output gradient: the chain
+    maxpool_bwd -> bn_backward(mask from scale*y+shift) -> stem wgrad on identical inputs."""
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(21)
+    N, H, Wd = 3, 64, 64
+    x = torch.randn(N, 3, H, Wd, generator=g)
+    w = bf(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    bn = torch.nn.BatchNorm2d(64)
+    bn.weight.data.uniform_(0.5, 1.5, generator=g)
+    bn.bias.data.uniform_(-0.3, 0.3, generator=g)
+    ref_bn = torch.nn.BatchNorm2d(64)
+    ref_bn.load_state_dict(bn.state_dict())
+    bn = bn.to(DEV)
+    wm = W(w, 7, 2, 3, stem=True)
+    xp = ops.pack_input(x.to(DEV))
+    y0 = ops.new_act(N, H // 2, Wd // 2, 64, DEV)
+    st = ops.bn_finalize(ops.stem_fwd(xp, wm.cw, y0, H, Wd), y0.npix, bn)
+    z0 = ops.new_act(N, H // 2, Wd // 2, 64, DEV)
+    ops.bn_apply(y0, st, z0, relu=True)
+    wide = ops.new_act(N, H // 4, Wd // 4, 128, DEV)          # pooled output lives in a channel window
+    pooled = wide.window(0, 64)
+    ops.maxpool_fwd(z0, pooled)
+    torch.cuda.synchronize()
+    # reference from the HIP path's own bf16 tensors: y0 (raw conv out) is the BN input
+    y0r = to_nchw(y0).requires_grad_(True)
+    z0r = F.relu(ref_bn(y0r))
+    z0q = z0r + (to_nchw(z0) - z0r).detach()                 # use exactly the stored (bf16) z0 for pooling ties
+    pr = F.max_pool2d(z0q, 3, 2, 1)
+    np.testing.assert_array_equal(to_nchw(wide)[:, :64].numpy(), pr.detach().numpy())
+    gp = bf(torch.randn(pr.shape, generator=g))
+    pr.backward(gp)
+    gwide = torch.zeros(N, 128, H // 4, Wd // 4)
+    gwide[:, :64] = gp
+    ga = nhwc_act(gwide)
+    dz0 = ops.new_act(N, H // 2, Wd // 2, 64, DEV)
+    ops.maxpool_bwd(z0, ga.window(0, 64), dz0)
+    dy0 = ops.new_act(N, H // 2, Wd // 2, 64, DEV)
+    dg, db = ops.bn_backward(dz0, y0, st, bn, dy0, 2)
+    torch.cuda.synchronize()
+    close(to_nchw(dy0), y0r.grad, rtol=2e-2, scale_atol=2e-2)
+    np.testing.assert_allclose(dg.cpu().numpy(), ref_bn.weight.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.weight.grad.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.bias.grad.abs().max()))

@@ -1,0 +1,231 @@
+"""Drop-in for the reference's ``backbones/OriginDenseNet.py`` on MI355X.
+
+``densenet121(pretrained=False, S=7)`` keeps the reference's state_dict keys
+(``features.{conv0,norm0,denseblock{k}.denselayer{i}.{norm1,conv1,norm2,conv2},
+transition{k}.{norm,conv},norm5}``, ``layer6``, ``bn_end`` -- OriginDenseNet.py:76-102) and the
+block configuration quirk S=7 -> (6,12,24,16,16), S=14 -> (6,12,24,16) (:159-161).
+
+MI355X-first differences to how the reference executes it:
+  * a dense block owns ONE NHWC buffer of its final width; each layer's 3x3 conv writes its 32
+    new channels straight into its slice, so ``torch.cat`` (:36), which re-copies the growing map
+    in every layer (O(L^2) traffic), does not exist;
+  * batch statistics of a channel do not depend on which BatchNorm reads it, so they are
+    computed ONCE when the channel is produced (conv epilogue) and kept in a per-block table that
+    every later ``norm1`` / transition ``norm`` / ``norm5`` finalises with its own gamma/beta;
+  * the backward accumulates the gradient of the shared buffer in place (one gradient buffer per
+    block), walking the layers in reverse.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from ..engine import ConvParam, HipBackbone, make_bn
+
+__all__ = ['DenseNet', 'densenet121']
+
+
+class _DenseLayer(nn.Module):
+    def __init__(self, cin, growth, bn_size):
+        super().__init__()
+        self.norm1 = make_bn(cin)
+        self.conv1 = ConvParam(cin, bn_size * growth, 1)
+        self.norm2 = make_bn(bn_size * growth)
+        self.conv2 = ConvParam(bn_size * growth, growth, 3, 1, 1)
+
+
+class _DenseBlock(nn.Module):
+    def __init__(self, num_layers, cin, bn_size, growth):
+        super().__init__()
+        for i in range(num_layers):
+            self.add_module('denselayer%d' % (i + 1), _DenseLayer(cin + i * growth, growth, bn_size))
+
+    def layers(self):
+        return list(self.children())
+
+
+class _Transition(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm = make_bn(cin)
+        self.conv = ConvParam(cin, cout, 1)
+
+
+class DenseNet(HipBackbone):
+    def __init__(self, growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4, B=2, S=7,
+                 num_classes=20):
+        super().__init__()
+        self.growth = growth_rate
+        self.out_channels = B * 5 + num_classes
+        feats = OrderedDict()
+        feats['conv0'] = ConvParam(3, num_init_features, 7, 2, 3)
+        feats['norm0'] = make_bn(num_init_features)
+        nf = num_init_features
+        self._plan = []                         # ("block", name, nf_in, n_layers) / ("trans", name, cin)
+        for i, nl in enumerate(block_config):
+            feats['denseblock%d' % (i + 1)] = _DenseBlock(nl, nf, bn_size, growth_rate)
+            self._plan.append(("block", 'denseblock%d' % (i + 1), nf, nl))
+            nf += nl * growth_rate
+            if i != len(block_config) - 1:
+                feats['transition%d' % (i + 1)] = _Transition(nf, nf // 2)
+                self._plan.append(("trans", 'transition%d' % (i + 1), nf))
+                nf //= 2
+        feats['norm5'] = make_bn(nf)
+        self.features = nn.Sequential(feats)
+        self.layer6 = ConvParam(nf, self.out_channels, 1)          # nf == 1024 for densenet121, the reference hard-wires it (:101)
+        self.bn_end = make_bn(self.out_channels)
+        for m in self.modules():                                    # :105-110
+            if isinstance(m, ConvParam):
+                nn.init.kaiming_normal_(m.weight)
+
+    # ------------------------------------------------------------------ forward executor
+    def _run_forward(self, images, train, save):
+        dev = images.device
+        N, _, H, W = images.shape
+        if H % 64 or W % 64:
+            raise _lib.Yv1Error("input height/width must be multiples of 64, got %dx%d" % (H, W))
+        F = self.features
+        bns = []
+
+        def norm(stats, count, bn, C=None):
+            if train:
+                bns.append(bn)
+                return ops.bn_finalize(stats, count, bn, C)
+            return ops.bn_eval_state(bn)
+
+        w0 = self.cw(F.conv0, stem=True)
+        xp = ops.pack_input(images)
+        y0 = ops.new_act(N, H // 2, W // 2, 64, dev)
+        s0 = norm(ops.stem_fwd(xp, w0, y0, H, W), y0.npix, F.norm0)
+        z0 = ops.new_act(N, H // 2, W // 2, 64, dev)
+        ops.bn_apply(y0, s0, z0, relu=True)
+        rec = {"stem": (xp, y0, s0, z0, H, W), "stages": []}
+
+        h, w = H // 4, W // 4
+        buf = table = None
+        pending_pool = ("max", z0)
+        for item in self._plan:
+            if item[0] == "block":
+                _, name, nf, nl = item
+                ctot = nf + nl * self.growth
+                buf = ops.new_act(N, h, w, ctot, dev)
+                first = buf.window(0, nf)
+                if pending_pool[0] == "max":
+                    ops.maxpool_fwd(pending_pool[1], first)
+                else:
+                    ops.avgpool_fwd(pending_pool[1], first)
+                table = None
+                if train:
+                    table = torch.empty((1, 2, ctot), dtype=torch.float32, device=dev)
+                    ops.stats_merge(ops.bn_stats(first), table[0], 0)
+                lrecs = []
+                for li, layer in enumerate(getattr(F, name).layers()):
+                    cin = nf + li * self.growth
+                    w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
+                    xin = buf.window(0, cin)
+                    st1 = norm(table, buf.npix, layer.norm1, cin)
+                    t1 = ops.new_act(N, h, w, cin, dev)
+                    ops.bn_apply(xin, st1, t1, relu=True)
+                    y1 = ops.new_act(N, h, w, w1.Opad, dev)
+                    st2 = norm(ops.conv_fwd(t1, w1, y1, train), y1.npix, layer.norm2)
+                    t2 = ops.new_act(N, h, w, w1.Opad, dev)
+                    ops.bn_apply(y1, st2, t2, relu=True)
+                    stats = ops.conv_fwd(t2, w2, buf.window(cin, self.growth), train)
+                    if train:
+                        ops.stats_merge(stats, table[0], cin)
+                    if save:
+                        lrecs.append((layer, cin, st1, t1, y1, st2, t2))
+                rec["stages"].append(("block", buf, lrecs, nf))
+            else:
+                _, name, cin = item
+                tr = getattr(F, name)
+                wc = self.cw(tr.conv)
+                st = norm(table, buf.npix, tr.norm, cin)
+                t = ops.new_act(N, h, w, cin, dev)
+                ops.bn_apply(buf, st, t, relu=True)
+                yc = ops.new_act(N, h, w, cin // 2, dev)
+                ops.conv_fwd(t, wc, yc, False)
+                rec["stages"].append(("trans", tr, buf, st, t, yc))
+                pending_pool = ("avg", yc)
+                h, w = h // 2, w // 2
+
+        st5 = norm(table, buf.npix, F.norm5, buf.C)
+        t5 = ops.new_act(N, h, w, buf.C, dev)
+        ops.bn_apply(buf, st5, t5, relu=True)
+        wh = self.cw(self.layer6)
+        yh = ops.new_act(N, h, w, wh.Opad, dev)
+        sh = norm(ops.conv_fwd(t5, wh, yh, train), yh.npix, self.bn_end, self.out_channels)
+        pred = ops.head_fwd(yh, sh, self.out_channels)
+        rec["head"] = (buf, st5, t5, yh, sh, pred)
+        if train:
+            self._bump_counters(bns)
+        return pred, (rec if save else None)
+
+    # ------------------------------------------------------------------ backward executor
+    def _run_backward(self, rec, gpred):
+        grads = {}
+        F = self.features
+        buf, st5, t5, yh, sh, pred = rec["head"]
+        dev = pred.device
+        N = yh.N
+        wh = self.cw(self.layer6)
+        dyh = ops.new_act(N, yh.H, yh.W, wh.Opad, dev)
+        grads[self.bn_end.weight], grads[self.bn_end.bias] = ops.head_bwd(gpred, pred, yh, sh, self.bn_end, dyh)
+        grads[self.layer6.weight] = ops.conv_wgrad(t5, dyh, wh)
+        dt5 = ops.new_act(N, t5.H, t5.W, t5.C, dev)
+        ops.conv_dgrad(dyh, wh, dt5)
+        G = ops.new_act(N, buf.H, buf.W, buf.C, dev)         # gradient of the last block's feature buffer
+        grads[F.norm5.weight], grads[F.norm5.bias] = ops.bn_backward(dt5, buf, st5, F.norm5, G, 2)
+        self._emit(grads, [self.bn_end.weight, self.bn_end.bias, self.layer6.weight, F.norm5.weight, F.norm5.bias])
+
+        for stage in reversed(rec["stages"]):
+            if stage[0] == "block":
+                _, buf, lrecs, nf = stage
+                for (layer, cin, st1, t1, y1, st2, t2) in reversed(lrecs):
+                    w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
+                    dy2 = G.window(cin, self.growth)          # the slice is complete: every later layer has added to it
+                    grads[layer.conv2.weight] = ops.conv_wgrad(t2, dy2, w2)
+                    dt2 = ops.new_act(N, t2.H, t2.W, t2.C, dev)
+                    ops.conv_dgrad(dy2, w2, dt2)
+                    dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
+                    grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward(dt2, y1, st2, layer.norm2, dy1, 2)
+                    grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1)
+                    dt1 = ops.new_act(N, t1.H, t1.W, cin, dev)
+                    ops.conv_dgrad(dy1, w1, dt1)
+                    grads[layer.norm1.weight], grads[layer.norm1.bias] = ops.bn_backward(
+                        dt1, buf.window(0, cin), st1, layer.norm1, G.window(0, cin), 2, accumulate=True)
+                    self._emit(grads, list(layer.parameters()))
+                g_first = G.window(0, nf)                     # gradient w.r.t. the pooled tensor that opened the block
+            else:
+                _, tr, buf, st, t, yc = stage
+                wc = self.cw(tr.conv)
+                dyc = ops.new_act(N, yc.H, yc.W, yc.C, dev)
+                ops.avgpool_bwd(g_first, dyc)
+                grads[tr.conv.weight] = ops.conv_wgrad(t, dyc, wc)
+                dt = ops.new_act(N, t.H, t.W, t.C, dev)
+                ops.conv_dgrad(dyc, wc, dt)
+                G = ops.new_act(N, buf.H, buf.W, buf.C, dev)
+                grads[tr.norm.weight], grads[tr.norm.bias] = ops.bn_backward(dt, buf, st, tr.norm, G, 2)
+                self._emit(grads, list(tr.parameters()))
+
+        xp, y0, s0, z0, H, W = rec["stem"]
+        w0 = self.cw(F.conv0, stem=True)
+        dz0 = ops.new_act(N, z0.H, z0.W, 64, dev)
+        ops.maxpool_bwd(z0, g_first, dz0)
+        dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
+        grads[F.norm0.weight], grads[F.norm0.bias] = ops.bn_backward(dz0, y0, s0, F.norm0, dy0, 2)
+        grads[F.conv0.weight] = ops.stem_wgrad(xp, dy0, w0, H, W)
+        self._emit(grads, [F.norm0.weight, F.norm0.bias, F.conv0.weight])
+        return grads
+
+
+def densenet121(pretrained=False, S=7, **kwargs):
+    """DenseNet-121 backbone + YOLO head (OriginDenseNet.py:149-164)."""
+    if S not in [7, 14]:
+        print('S musk be 7x7 or 14x14')
+        exit()
+    if pretrained:
+        raise _lib.Yv1Error("pretrained=True would download from download.pytorch.org; load a state_dict instead")
+    cfg = (6, 12, 24, 16, 16) if S == 7 else (6, 12, 24, 16)
+    return DenseNet(num_init_features=64, growth_rate=32, block_config=cfg, **kwargs)
