@@ -51,11 +51,12 @@ def main():
     ap.add_argument("--S", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-sgd", type=int, default=1)
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     args = ap.parse_args()
 
     from yolo_v1_amd import distributed as ydist
     from yolo_v1_amd import _lib
-    from yolo_v1_amd.train import build, learning_rate_policy, train_step
+    from yolo_v1_amd.train import GraphedStep, build, learning_rate_policy, train_step
     from yolo_v1_amd.utils.YOLODataLoader import synthetic_batch
     _lib.lib()                                   # fail loudly if the HIP library is missing
     rank, world, device = ydist.init_from_env()
@@ -75,15 +76,25 @@ def main():
     lr_map = {1: 0.001, 75: 0.0001, 115: 0.00001}
 
     lr, it = 0.0, 0
+    use_graph = bool(args.graph) and bool(args.fused_sgd)
+    graphed = None
+    if use_graph:
+        for g in opt.param_groups:
+            g['lr'] = 1e-6
+        graphed = GraphedStep(net, loss_layer, opt, images, target, sync, warmup=min(3, max(1, args.warmup)))
+        it = graphed.steps_done
+        lr = it * 1e-6
 
     def step():
         nonlocal lr, it
         it += 1
         lr = learning_rate_policy(it, 0, lr, lr_map)
+        if graphed is not None:
+            return graphed(lr)
         return train_step(net, loss_layer, opt, images, target, lr, sync)
 
-    for _ in range(args.warmup):
-        loss = step()
+    for _ in range(max(0, args.warmup - (graphed.steps_done if graphed else 0))):
+        step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -122,7 +133,8 @@ def main():
                                    % ("ResNet-50" if args.backbone == "resnet" else "DenseNet-121", args.S, args.batch,
                                       "+RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "optimizer": "fused HIP SGD" if args.fused_sgd else "torch.optim.SGD"},
+                       "optimizer": "fused HIP SGD" if args.fused_sgd else "torch.optim.SGD",
+                       "launch": "hipGraph replay of the whole step" if use_graph else "eager launches"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "note": "whole training step of one GPU: %.2f algorithmic conv GFLOP/img x %d img / %.3f ms "

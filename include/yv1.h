@@ -103,9 +103,12 @@ int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const voi
                      int accumulate, yv1_stream_t stream);
 
 /* ---- pooling and head: OriginResNet.py:125,:188-189; OriginDenseNet.py:54,:80,:127-128 --------------------- */
-int yv1_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, yv1_stream_t stream);
-int yv1_maxpool3x3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C,
+/* idx (nullable): uint8 [N,OH,OW,C] = window position of the first maximum (torch's tie rule), for the backward */
+int yv1_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, void* idx, int N, int H, int W, int C,
                          yv1_stream_t stream);
+/* give idx (fast) or x (the forward input; the first maximum is re-derived) */
+int yv1_maxpool3x3s2_bwd(const void* x, int ldx, const void* idx, const void* dy, int lddy, void* dx, int lddx, int N, int H,
+                         int W, int C, yv1_stream_t stream);
 int yv1_avgpool2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, yv1_stream_t stream);
 int yv1_avgpool2_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, yv1_stream_t stream);
 int yv1_head_sigmoid_fwd(const void* y, int ldy, const float* scale, const float* shift, float* out, long long npix,
@@ -121,6 +124,13 @@ int yv1_prep_stem_weights(const float* w, long long so, long long si, long long 
                           yv1_stream_t stream);
 int yv1_unpack_stem_grad(const float* g, float* dw, long long so, long long si, long long sh, long long sw, int O,
                          yv1_stream_t stream);
+
+/* ---- optimizer: torch.optim.SGD(momentum=0.99).step(), train.py:84,:172 ------------------------------------ */
+int yv1_sgd_max_tensors(void);
+/* buf = momentum*buf + grad_scale*g ; w -= (*lr)*buf over `count` dense fp32 tensors.  w/g/m/n are HOST arrays
+ * (of device pointers / element counts); *lr is read on the device so the step can live in a hipGraph. */
+int yv1_sgd_momentum_step(float* const* w, const float* const* g, float* const* m, const long long* n, int count,
+                          const float* lr, float momentum, float grad_scale, yv1_stream_t stream);
 
 #ifdef __cplusplus
 }

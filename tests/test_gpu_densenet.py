@@ -122,7 +122,7 @@ def test_densenet121_every_layer_teacher_forced():
         assert rel <= 1e-2, "%s: rel err %.3g" % (name, rel)
 
     bnf = lambda t, k: F.batch_norm(t, None, None, P[k + ".weight"], P[k + ".bias"], True)
-    xp, y0, s0, z0, H, W = rec["stem"]
+    xp, y0, s0, z0, H, W = rec["stem"][:6]
     chk("stem conv", nchw(y0), F.conv2d(x.to(torch.bfloat16).float(), bfw("features.conv0.weight"), stride=2, padding=3))
     chk("stem bn", nchw(z0), F.relu(bnf(nchw(y0), "features.norm0")))
     bi, prev_yc = 0, None

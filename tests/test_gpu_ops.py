@@ -182,7 +182,7 @@ def test_pools():
     x = bf(F.relu(torch.randn(2, 64, 14, 18, generator=g)))     # post-ReLU: many exact ties at 0
     xa = nhwc_act(x)
     ya = ops.new_act(2, 7, 9, 64, DEV)
-    ops.maxpool_fwd(xa, ya)
+    pidx = ops.maxpool_fwd(xa, ya, want_index=True)
     xr = x.clone().requires_grad_(True)
     yr = F.max_pool2d(xr, 3, 2, 1)
     torch.cuda.synchronize()
@@ -190,9 +190,12 @@ def test_pools():
     gy = bf(torch.randn(yr.shape, generator=g))
     yr.backward(gy)
     dxa = ops.new_act(2, 14, 18, 64, DEV)
-    ops.maxpool_bwd(xa, nhwc_act(gy), dxa)
+    ops.maxpool_bwd(xa, nhwc_act(gy), dxa)                       # first maximum re-derived from x
+    dxb = ops.new_act(2, 14, 18, 64, DEV)
+    ops.maxpool_bwd(None, nhwc_act(gy), dxb, pidx)               # saved arg-max index (the training path)
     torch.cuda.synchronize()
     close(to_nchw(dxa), xr.grad, rtol=1e-2, scale_atol=1e-2)
+    np.testing.assert_array_equal(to_nchw(dxb).numpy(), to_nchw(dxa).numpy())
     # average pool
     x2 = bf(torch.randn(2, 128, 8, 6, generator=g))
     x2a = nhwc_act(x2)

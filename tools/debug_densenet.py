@@ -27,7 +27,7 @@ def rep(name, got, want, show=False):
     if show or rel > 1e-2:
         print("%-50s rel %.4g |want| %.3g" % (name, rel, float(want.abs().max())))
 bnf = lambda t, k: F.batch_norm(t, None, None, P[k + ".weight"], P[k + ".bias"], True)
-xp, y0, s0, z0, H, W = rec["stem"]
+xp, y0, s0, z0, H, W = rec["stem"][:6]
 rep("stem conv", nchw(y0), F.conv2d(x.to(torch.bfloat16).float(), bfw("features.conv0.weight"), stride=2, padding=3), True)
 rep("stem bn", nchw(z0), F.relu(bnf(nchw(y0), "features.norm0")), True)
 bi = 0

@@ -54,8 +54,8 @@ SIGNATURES = {
     "yv1_bn_bwd_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i,
                                c_p, c_i, c_p, c_i, c_i, c_p]),
     "yv1_stats_merge": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p]),
-    "yv1_maxpool3x3s2_fwd": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "yv1_maxpool3x3s2_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_maxpool3x3s2_fwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_maxpool3x3s2_bwd": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "yv1_avgpool2_fwd": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "yv1_avgpool2_bwd": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "yv1_head_sigmoid_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_ll, c_i, c_p]),
@@ -63,6 +63,9 @@ SIGNATURES = {
     "yv1_prep_weights": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "yv1_prep_stem_weights": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p, c_p]),
     "yv1_unpack_stem_grad": (c_i, [c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p]),
+    # optim.hip
+    "yv1_sgd_max_tensors": (c_i, []),
+    "yv1_sgd_momentum_step": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_f, c_f, c_p]),
 }
 
 

@@ -100,7 +100,7 @@ class DenseNet(HipBackbone):
         s0 = norm(ops.stem_fwd(xp, w0, y0, H, W), y0.npix, F.norm0)
         z0 = ops.new_act(N, H // 2, W // 2, 64, dev)
         ops.bn_apply(y0, s0, z0, relu=True)
-        rec = {"stem": (xp, y0, s0, z0, H, W), "stages": []}
+        rec = {"stem": [xp, y0, s0, z0, H, W, None], "stages": []}
 
         h, w = H // 4, W // 4
         buf = table = None
@@ -112,7 +112,7 @@ class DenseNet(HipBackbone):
                 buf = ops.new_act(N, h, w, ctot, dev)
                 first = buf.window(0, nf)
                 if pending_pool[0] == "max":
-                    ops.maxpool_fwd(pending_pool[1], first)
+                    rec["stem"][6] = ops.maxpool_fwd(pending_pool[1], first, want_index=save)
                 else:
                     ops.avgpool_fwd(pending_pool[1], first)
                 table = None
@@ -209,10 +209,10 @@ class DenseNet(HipBackbone):
                 grads[tr.norm.weight], grads[tr.norm.bias] = ops.bn_backward(dt, buf, st, tr.norm, G, 2)
                 self._emit(grads, list(tr.parameters()))
 
-        xp, y0, s0, z0, H, W = rec["stem"]
+        xp, y0, s0, z0, H, W, pidx = rec["stem"]
         w0 = self.cw(F.conv0, stem=True)
         dz0 = ops.new_act(N, z0.H, z0.W, 64, dev)
-        ops.maxpool_bwd(z0, g_first, dz0)
+        ops.maxpool_bwd(z0, g_first, dz0, pidx)
         dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
         grads[F.norm0.weight], grads[F.norm0.bias] = ops.bn_backward(dz0, y0, s0, F.norm0, dy0, 2)
         grads[F.conv0.weight] = ops.stem_wgrad(xp, dy0, w0, H, W)

@@ -100,8 +100,8 @@ class ResNet(HipBackbone):
         z0 = ops.new_act(N, H // 2, W // 2, 64, dev)
         ops.bn_apply(y0, s0, z0, relu=True)
         x = ops.new_act(N, H // 4, W // 4, 64, dev)
-        ops.maxpool_fwd(z0, x)
-        rec["stem"] = (xp, y0, s0, z0, H, W)
+        pidx = ops.maxpool_fwd(z0, x, want_index=save)
+        rec["stem"] = (xp, y0, s0, z0, H, W, pidx)
 
         for blk in self._blocks():
             w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
@@ -188,10 +188,10 @@ class ResNet(HipBackbone):
             self._emit(grads, list(blk.parameters()))
             g = g_in
 
-        xp, y0, s0, z0, H, W = rec["stem"]
+        xp, y0, s0, z0, H, W, pidx = rec["stem"]
         w0 = self.cw(self.conv1, stem=True)
         dz0 = ops.new_act(N, z0.H, z0.W, 64, dev)
-        ops.maxpool_bwd(z0, g, dz0)
+        ops.maxpool_bwd(z0, g, dz0, pidx)
         dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
         grads[self.bn1.weight], grads[self.bn1.bias] = ops.bn_backward(dz0, y0, s0, self.bn1, dy0, 2)
         grads[self.conv1.weight] = ops.stem_wgrad(xp, dy0, w0, H, W)

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
 
 // ------------------------------------------------------------------ max pool 3x3 / stride 2 / pad 1
 __global__ void __launch_bounds__(256) k_maxpool_fwd(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
-                                                     int N, int H, int W, int C) {
+                                                     unsigned char* __restrict__ idx, int N, int H, int W, int C) {
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1, CH = C >> 3;
   const long long total = (long long)N * OH * OW * CH;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -326,8 +326,9 @@ __global__ void __launch_bounds__(256) k_maxpool_fwd(const bf16_t* __restrict__ 
     const int oh = (int)(t % OH);
     const int n = (int)(t / OH);
     float m[8];
+    unsigned am[8];                      // window position (r*3+s) of the FIRST maximum, the element torch selects
 #pragma unroll
-    for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+    for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; am[k] = 0; }
     for (int r = 0; r < 3; ++r) {
       const int h = oh * 2 - 1 + r;
       if (h < 0 || h >= H) continue;
@@ -337,10 +338,17 @@ __global__ void __launch_bounds__(256) k_maxpool_fwd(const bf16_t* __restrict__ 
         float f[8];
         unpack8(*reinterpret_cast<const u32x4*>(x + ((size_t)(n * H + h) * W + w) * ldx + cc), f);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], f[k]);
+        for (int k = 0; k < 8; ++k)
+          if (f[k] > m[k]) { m[k] = f[k]; am[k] = r * 3 + s; }
       }
     }
     *reinterpret_cast<u32x4*>(y + ((size_t)(n * OH + oh) * OW + ow) * ldy + cc) = pack8(m);
+    if (idx) {
+      uint2 o;
+      o.x = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+      o.y = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+      *reinterpret_cast<uint2*>(idx + ((size_t)(n * OH + oh) * OW + ow) * C + cc) = o;
+    }
   }
 }
 
@@ -386,6 +394,39 @@ __global__ void __launch_bounds__(256) k_maxpool_bwd(const bf16_t* __restrict__ 
         unpack8(*reinterpret_cast<const u32x4*>(dy + ((size_t)(n * OH + oh) * OW + ow) * lddy + cc), d);
 #pragma unroll
         for (int k = 0; k < 8; ++k) g[k] += first[k] ? d[k] : 0.f;
+      }
+    *reinterpret_cast<u32x4*>(dx + ((size_t)(n * H + h) * W + w) * lddx + cc) = pack8(g);
+  }
+}
+
+// index form: the forward stored, per (window, channel), which of its 9 positions was the first maximum
+__global__ void __launch_bounds__(256) k_maxpool_bwd_idx(const unsigned char* __restrict__ idx, const bf16_t* __restrict__ dy,
+                                                         int lddy, bf16_t* __restrict__ dx, int lddx, int N, int H, int W, int C) {
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1, CH = C >> 3;
+  const long long total = (long long)N * H * W * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % CH) * 8;
+    long long t = i / CH;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = 0.f;
+    const int oh_lo = h / 2, oh_hi = min(OH - 1, (h + 1) / 2);
+    const int ow_lo = w / 2, ow_hi = min(OW - 1, (w + 1) / 2);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const unsigned code = (unsigned)((h - (oh * 2 - 1)) * 3 + (w - (ow * 2 - 1)));
+        const size_t o = (size_t)(n * OH + oh) * OW + ow;
+        const uint2 a = *reinterpret_cast<const uint2*>(idx + o * C + cc);
+        float d[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dy + o * lddy + cc), d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned am = ((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xffu;
+          g[k] += am == code ? d[k] : 0.f;
+        }
       }
     *reinterpret_cast<u32x4*>(dx + ((size_t)(n * H + h) * W + w) * lddx + cc) = pack8(g);
   }
@@ -670,20 +711,28 @@ extern "C" int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz
   return YV1_OK;
 }
 
-extern "C" int yv1_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, hipStream_t stream) {
+// idx (nullable): uint8 [N,OH,OW,C], window position (r*3+s) of the first maximum, consumed by the backward
+extern "C" int yv1_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, void* idx, int N, int H, int W, int C,
+                                    hipStream_t stream) {
   if (!x || !y || N <= 0 || C % 8 || ldx % 8 || ldy % 8) return YV1_ERR_BAD_ARG;
   const long long total = (long long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 8);
-  hipLaunchKernelGGL(k_maxpool_fwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, H, W, C);
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
+                     (unsigned char*)idx, N, H, W, C);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
 
-extern "C" int yv1_maxpool3x3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W,
-                                    int C, hipStream_t stream) {
-  if (!x || !dy || !dx || N <= 0 || C % 8 || ldx % 8 || lddy % 8 || lddx % 8) return YV1_ERR_BAD_ARG;
+// Either idx (from the forward) or x (the forward input: the first maximum is re-derived) must be given.
+extern "C" int yv1_maxpool3x3s2_bwd(const void* x, int ldx, const void* idx, const void* dy, int lddy, void* dx, int lddx, int N,
+                                    int H, int W, int C, hipStream_t stream) {
+  if ((!x && !idx) || !dy || !dx || N <= 0 || C % 8 || (x && ldx % 8) || lddy % 8 || lddx % 8) return YV1_ERR_BAD_ARG;
   const long long total = (long long)N * H * W * (C / 8);
-  hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
-                     (bf16_t*)dx, lddx, N, H, W, C);
+  if (idx)
+    hipLaunchKernelGGL(k_maxpool_bwd_idx, dim3(ew_blocks(total)), dim3(256), 0, stream, (const unsigned char*)idx,
+                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, H, W, C);
+  else
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
+                       (bf16_t*)dx, lddx, N, H, W, C);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }

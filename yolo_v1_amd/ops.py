@@ -42,6 +42,15 @@ def _f32(n, device):
 
 
 # ------------------------------------------------------------------ weights
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Tell the bf16 shadow copies that parameters were modified by a raw kernel (fused optimizer,
+    graph replay) that did not go through torch's version counter."""
+    _WEIGHT_EPOCH[0] += 1
+
+
 class ConvWeights:
     """bf16 shadow copies of one fp32 OIHW parameter, refreshed when the parameter changes:
     ``fwd`` [Opad][taps][Ipad] and ``tr`` [Ipad][taps][Opad] (dgrad operand)."""
@@ -60,7 +69,7 @@ class ConvWeights:
 
     def refresh(self):
         p = self.param
-        ver = p._version
+        ver = (p._version, _WEIGHT_EPOCH[0])
         if self.fwd is not None and ver == self.version and self.fwd.device == p.device:
             return
         dev = p.device
@@ -257,13 +266,18 @@ def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=Fals
 
 
 # ------------------------------------------------------------------ pooling / head
-def maxpool_fwd(x, y):
-    check(lib().yv1_maxpool3x3s2_fwd(x.p, x.ld, y.p, y.ld, x.N, x.H, x.W, x.C, stream_ptr(x.t.device)), "yv1_maxpool3x3s2_fwd")
+def maxpool_fwd(x, y, want_index=False):
+    """3x3/2 max pool; with want_index returns the uint8 first-argmax tensor the backward consumes."""
+    idx = torch.empty((y.N, y.H, y.W, x.C), dtype=torch.uint8, device=x.t.device) if want_index else None
+    check(lib().yv1_maxpool3x3s2_fwd(x.p, x.ld, y.p, y.ld, ptr(idx), x.N, x.H, x.W, x.C, stream_ptr(x.t.device)),
+          "yv1_maxpool3x3s2_fwd")
+    return idx
 
 
-def maxpool_bwd(x, dy, dx):
-    check(lib().yv1_maxpool3x3s2_bwd(x.p, x.ld, dy.p, dy.ld, dx.p, dx.ld, x.N, x.H, x.W, x.C, stream_ptr(x.t.device)),
-          "yv1_maxpool3x3s2_bwd")
+def maxpool_bwd(x, dy, dx, idx=None):
+    """x: the forward input (used when idx is None); dx has x's geometry."""
+    check(lib().yv1_maxpool3x3s2_bwd(x.p if x is not None else None, x.ld if x is not None else 0, ptr(idx), dy.p, dy.ld,
+                                     dx.p, dx.ld, dx.N, dx.H, dx.W, dx.C, stream_ptr(dx.t.device)), "yv1_maxpool3x3s2_bwd")
 
 
 def avgpool_fwd(x, y):

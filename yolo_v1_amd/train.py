@@ -76,6 +76,67 @@ def train_step(net, loss_layer, optimizer, images, target, lr, grad_sync=None):
     return loss
 
 
+class GraphedStep:
+    """The loop body of train.py:158-172 captured once into a hipGraph and replayed.
+
+    A training step is ~800 short kernel launches; issued one by one from Python the GPU idles ~20 %
+    of the step waiting for the host.  Captured, one ``hipGraphLaunch`` replays them all.  What makes the
+    step capturable: static input buffers (copy each batch into ``.images`` / ``.target``), the
+    learning rate in device memory (``FusedSGD``), no host sync inside (``_quiet`` loss layer).
+    With several ranks the graph holds forward+loss+backward; the RCCL gradient average and the fused
+    optimizer step run right after the replay.
+    """
+
+    def __init__(self, net, loss_layer, optimizer, images, target, grad_sync=None, warmup=3):
+        from .optim import FusedSGD
+        if not isinstance(optimizer, FusedSGD):
+            raise TypeError("GraphedStep needs yolo_v1_amd.optim.FusedSGD (device-side learning rate)")
+        self.net, self.loss_layer, self.opt, self.sync = net, loss_layer, optimizer, grad_sync
+        self.images, self.target = images, target
+        self.loss_layer.quiet = True
+        self.in_graph_step = grad_sync is None
+        if grad_sync is not None:
+            net.set_grad_ready_hook(None)          # buckets are issued after the replay, not from inside the capture
+        self.steps_done = 0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up on a side stream: lazy inits, allocator, hipFuncSetAttribute
+            for _ in range(warmup):
+                self._body(eager=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body(eager=False)
+
+    def _body(self, eager):
+        pred = self.net(self.images)
+        loss = self.loss_layer(pred, self.target)
+        self.opt.zero_grad()
+        loss.backward()
+        if self.in_graph_step:
+            self.opt.step()
+        elif eager:
+            self._sync_and_step()
+        if eager:
+            self.steps_done += 1
+        return loss
+
+    def _sync_and_step(self):
+        self.sync.on_ready([(p, p.grad) for p in self.net.parameters() if p.grad is not None])
+        self.sync.finish()
+        self.opt.step()
+
+    def __call__(self, lr):
+        from . import ops
+        self.opt.set_lr(lr)
+        self.graph.replay()
+        ops.bump_weight_epoch()
+        if not self.in_graph_step:
+            self._sync_and_step()
+        return self.loss
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="YOLO-v1 training on MI355X (reference train.py surface)")
     ap.add_argument("--backbone", default=DEFAULTS["backbone"], choices=["densenet", "resnet"])
