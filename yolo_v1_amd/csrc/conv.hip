@@ -29,6 +29,8 @@
 // Cout tiles of the same pixel tile back to back, so the gathered A rows are re-read from that
 // XCD's L2, not from HBM.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -50,7 +52,15 @@ struct ConvArgs {
   int accumulate;
   int M;
   int MT, NT;
+  int dbg;             // tuning only: bit0 skip the in-loop global loads / LDS stores, bit1 skip the MFMA block
 };
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 template <int BK>
 __device__ __forceinline__ int swz(int row, int chunk) {
@@ -59,9 +69,10 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
-__global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_gemm(ConvArgs a) {
+  constexpr int NTH = WM * WN * 64;           // threads per workgroup (one wave per (wm, wn))
   constexpr int CPR = BK / 8;
-  constexpr int ROWS_PER_PASS = 256 / CPR;
+  constexpr int ROWS_PER_PASS = NTH / CPR;
   constexpr int A_PASSES = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
   constexpr int B_PASSES = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
   constexpr bool A_GUARD = (BM % ROWS_PER_PASS) != 0, B_GUARD = (BN % ROWS_PER_PASS) != 0;
@@ -88,12 +99,12 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
   // ---- per-thread loader state
   const int ccol = tid % CPR;          // chunk column inside the K-step
   const int rrow = tid / CPR;          // first row handled
-  int pix_base[A_PASSES];              // image base (n*IH*IW) or -1 when the row is past M
+  int pix_base[A_PASSES];              // image base (n*IH*IW) or -1 when the row is past M / past the tile
   int ph[A_PASSES], qw[A_PASSES];      // p*ah + ch , q*aw + cw
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int m = m0 + rrow + i * ROWS_PER_PASS;
-    if (m < a.M) {
+    if (m < a.M && (!A_GUARD || rrow + i * ROWS_PER_PASS < BM)) {
       const int pq = a.P * a.Q;
       const int n = m / pq, rem = m - n * pq;
       const int p = rem / a.Q, q = rem - p * a.Q;
@@ -108,31 +119,51 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
   const int cblocks = a.Cin / BK;
   const int nk = a.R * a.S * cblocks;
   const int dmask = (1 << a.log2d) - 1;
+  // weights: K is walked contiguously (tap-major, then channel block) -> one running offset
+  // (32-bit element offsets: every tensor here is far below 2^31 elements; keeps the VGPR count down)
+  int woff[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int row = rrow + i * ROWS_PER_PASS;
+    woff[i] = (n0 + ((!B_GUARD || row < BN) ? row : 0)) * Ktot + ccol * 8;
+  }
 
-  u32x4 ra[A_PASSES], rb[B_PASSES];
-
-#define YV1_LOAD_TILES(KT_)                                                                                      \
+  // The loader runs one K-step ahead of the MFMA block.  Its tap state (source offset of each row
+  // for the current filter tap, or "padding") is recomputed only when the tap changes, not per step.
+  int ld_r = 0, ld_s = 0, ld_cb = 0;
+  int aoff[A_PASSES];                  // element offset of the tapped pixel + chunk column; 0 when the tap is padding
+  unsigned avalid = 0;                 // bit i: row i of this thread reads real data for the current tap
+#define YV1_SET_TAP()                                                                                            \
   {                                                                                                              \
-    const int kt__ = (KT_);                                                                                      \
-    const int tap = kt__ / cblocks, cb = kt__ - tap * cblocks;                                                   \
-    const int r = tap / a.S, s = tap - r * a.S;                                                                  \
-    const int koff = cb * BK + ccol * 8;                                                                         \
+    avalid = 0;                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
-      const int hn = ph[i] + r * a.bh, wn_ = qw[i] + s * a.bw;                                                   \
+      const int hn = ph[i] + ld_r * a.bh, wn_ = qw[i] + ld_s * a.bw;                                             \
       const int ih = hn >> a.log2d, iw = wn_ >> a.log2d;                                                         \
-      const bool ok = (!A_GUARD || rrow + i * ROWS_PER_PASS < BM) && pix_base[i] >= 0 &&                         \
-                      ((hn | wn_) & dmask) == 0 && hn >= 0 && wn_ >= 0 && ih < a.IH && iw < a.IW;                \
-      const size_t off = ok ? (size_t)(pix_base[i] + ih * a.IW + iw) * a.ldx + koff : 0;                         \
-      u32x4 v = {0u, 0u, 0u, 0u};                                                                                \
-      if (ok) v = *reinterpret_cast<const u32x4*>(a.X + off);                                                    \
-      ra[i] = v;                                                                                                 \
+      const bool ok = pix_base[i] >= 0 && ((hn | wn_) & dmask) == 0 && hn >= 0 && wn_ >= 0 && ih < a.IH &&       \
+                      iw < a.IW;                                                                                 \
+      aoff[i] = ok ? (pix_base[i] + ih * a.IW + iw) * a.ldx + ccol * 8 : 0;                                      \
+      avalid |= ok ? (1u << i) : 0u;                                                                             \
+    }                                                                                                            \
+  }
+  u32x4 ra[A_PASSES], rb[B_PASSES];
+  // branch-free: padded taps load a dummy (valid) address and are zeroed with a select
+#define YV1_LOAD_TILES()                                                                                         \
+  {                                                                                                              \
+    const int coff = ld_cb * BK;                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const bool ok = (avalid >> i) & 1u;                                                                        \
+      u32x4 v = *reinterpret_cast<const u32x4*>(a.X + (aoff[i] + (ok ? coff : 0)));                              \
+      const u32x4 z = {0u, 0u, 0u, 0u};                                                                          \
+      ra[i] = ok ? v : z;                                                                                        \
     }                                                                                                            \
     _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
-      const int n = n0 + rrow + i * ROWS_PER_PASS;                                                               \
-      const bool ok = !B_GUARD || rrow + i * ROWS_PER_PASS < BN;                                                 \
-      u32x4 v = {0u, 0u, 0u, 0u};                                                                                \
-      if (ok) v = *reinterpret_cast<const u32x4*>(a.W + (size_t)n * Ktot + (size_t)tap * a.Cin + koff);         \
-      rb[i] = v;                                                                                                 \
+      rb[i] = *reinterpret_cast<const u32x4*>(a.W + woff[i]);                                                    \
+      woff[i] += BK;                                                                                             \
+    }                                                                                                            \
+    if (++ld_cb == cblocks) {                                                                                    \
+      ld_cb = 0;                                                                                                 \
+      if (++ld_s == a.S) { ld_s = 0; ++ld_r; }                                                                   \
+      YV1_SET_TAP();                                                                                             \
     }                                                                                                            \
   }
 #define YV1_STORE_TILES(BUF_)                                                                                    \
@@ -157,16 +188,19 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  YV1_LOAD_TILES(0);
+  YV1_SET_TAP();
+  YV1_LOAD_TILES();
   YV1_STORE_TILES(0);
   __syncthreads();
 
   const int l31 = lane & 31, lh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) YV1_LOAD_TILES(kt + 1);      // global loads in flight during the MFMA block
+    const bool do_ld = (kt + 1 < nk) && !(a.dbg & 1);
+    if (do_ld) YV1_LOAD_TILES();                  // global loads in flight during the MFMA block
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + A_BYTES;
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 fa[TM], fb[TN];
@@ -186,7 +220,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) YV1_STORE_TILES(cur ^ 1);
+    if (do_ld) YV1_STORE_TILES(cur ^ 1);
     __syncthreads();
   }
 
@@ -215,8 +249,11 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
     }
   }
 
-  // ---- epilogue 2: accumulators -> bf16 tile in LDS (pairs of channels packed via a lane swap)
+  // ---- epilogue 2: accumulators -> bf16 tile in LDS.  A lane holds ONE channel (column) of 16 pixel rows;
+  // neighbouring lanes swap one value (DPP quad_perm, no LDS traffic) so each lane owns a 2-channel pair,
+  // rounded by v_cvt_pk_bf16_f32 and written as one dword.
   unsigned char* et = smem;
+  const bool odd = lane & 1;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -226,14 +263,14 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         const float mine_lo = acc[i][j][e], mine_hi = acc[i][j][e + 1];
-        const bool odd = lane & 1;
         const float send = odd ? mine_lo : mine_hi;
-        const float recv = __shfl_xor(send, 1, 64);
-        // even lane: row(e), cols (col, col+1) = (mine_lo, partner's acc[e]) ; odd: row(e+1), cols (col-1, col)
+        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
+        // even lane: row(e), channels (col, col+1) = (mine_lo, neighbour's acc[e]); odd: row(e+1), (col-1, col)
         const int row = rbase + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2);
-        const unsigned v = odd ? pack_bf16x2(recv, mine_hi) : pack_bf16x2(mine_lo, recv);
+        const unsigned v = odd ? cvt_pk_bf16(recv, mine_hi) : cvt_pk_bf16(mine_lo, recv);
         *reinterpret_cast<unsigned*>(et + row * EPI_PITCH + (col & ~1) * 2) = v;
       }
+      __builtin_amdgcn_sched_barrier(0);   // one 32x32 block at a time: keeps the accumulator->VGPR copies short-lived
     }
   __syncthreads();
 
@@ -251,17 +288,22 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs a) {
 
   // ---- epilogue 3: full-line stores, 16 B (8 channels) per lane
   constexpr int OCPR = BN / 8;
-  constexpr int OPASSES = (BM * OCPR + 255) / 256;
+  constexpr int OPASSES = (BM * OCPR + NTH - 1) / NTH;
 #pragma unroll
   for (int i = 0; i < OPASSES; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NTH;
     const int row = idx / OCPR, cc = idx - row * OCPR;
     const int m = m0 + row;
     if (row < BM && m < a.M) {
-      const int pq = a.P * a.Q;
-      const int n = m / pq, rem = m - n * pq;
-      const int p = rem / a.Q, q = rem - p * a.Q;
-      const size_t off = ((size_t)(n * a.OH + p * a.os) * a.OW + q * a.os) * a.ldy + n0 + cc * 8;
+      size_t off;
+      if (a.os == 1) {                       // destination pixels are the GEMM pixels in order
+        off = (size_t)m * a.ldy + n0 + cc * 8;
+      } else {
+        const int pq = a.P * a.Q;
+        const int n = m / pq, rem = m - n * pq;
+        const int p = rem / a.Q, q = rem - p * a.Q;
+        off = ((size_t)(n * a.OH + p * a.os) * a.OW + q * a.os) * a.ldy + n0 + cc * 8;
+      }
       uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
       if (a.accumulate) {
         const uint4 o = *reinterpret_cast<const uint4*>(a.Y + off);
@@ -288,33 +330,66 @@ int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
-  const size_t lds = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+  // single-K-step problems (1x1 conv with Cin == BK) never touch the second staging buffer: a smaller LDS
+  // request lets more workgroups share a CU, which is what these load->few-MFMA->store kernels need
+  const int nk = a.R * a.S * (a.Cin / BK);
+  const size_t stage_bytes = (size_t)(nk > 1 ? 2 : 1) * STAGE;
+  const size_t lds = stage_bytes > (size_t)EPI ? stage_bytes : (size_t)EPI;
   auto kern = k_conv_gemm<BM, BN, BK, WM, WN>;
-  if (lds > 64 * 1024) {
+  constexpr size_t MAXLDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+  if (MAXLDS > 64 * 1024) {
     static bool once = false;
     if (!once) {
-      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAXLDS));
       once = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), lds, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
 
+// tile choice shared by dispatch() and yv1_conv2d_stats_rows(): returns BM
+int choose_cfg(int M, int Cout, int Cin, int* bn) {
+  static int forced = -2;
+  if (forced == -2) {                       // debug/tuning override: YV1_CONV_CFG=<BM>x<BN>
+    const char* e = getenv("YV1_CONV_CFG");
+    forced = -1;
+    if (e) { int m = 0, n = 0; if (sscanf(e, "%dx%d", &m, &n) == 2) forced = m * 1000 + n; }
+  }
+  if (forced > 0) {
+    const int fm = forced / 1000, fn = forced % 1000;
+    if (Cout % fn == 0 && (Cin % 64) == 0) { *bn = fn; return fm; }
+  }
+  // measured per layer on MI355X (tools/bench_conv.py sweep): 128x128 wins whenever it yields >= ~200 tiles,
+  // below that (7x7 feature maps) 64x64 fills the 256 CUs better
+  const long long tiles128 = (long long)((M + 127) / 128) * ((Cout + 127) / 128);
+  if (Cout % 128 == 0 && tiles128 >= 192) { *bn = 128; return 128; }
+  if (Cout % 64 == 0) {
+    const long long tiles = (long long)((M + 127) / 128) * (Cout / 64);
+    *bn = 64;
+    return tiles >= 512 ? 128 : 64;
+  }
+  *bn = 32;
+  return 128;
+}
+
 int dispatch(ConvArgs& a, hipStream_t stream) {
   if (a.Cin % 32 || a.Cout % 32 || a.ldx % 8 || a.ldy % 8) return YV1_ERR_UNSUPPORTED;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("YV1_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
+  }
   const bool k64 = (a.Cin % 64) == 0;
-  const long long tiles128 = (long long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-  if (a.Cout % 128 == 0 && tiles128 >= 512) {
-    return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
-  }
-  if (a.Cout % 64 == 0) {
-    const long long tiles = (long long)((a.M + 127) / 128) * (a.Cout / 64);
-    if (tiles >= 512) return k64 ? launch<128, 64, 64, 2, 2>(a, stream) : launch<128, 64, 32, 2, 2>(a, stream);
-    return k64 ? launch<64, 64, 64, 2, 2>(a, stream) : launch<64, 64, 32, 2, 2>(a, stream);
-  }
-  return k64 ? launch<128, 32, 64, 4, 1>(a, stream) : launch<128, 32, 32, 4, 1>(a, stream);
+  int bn = 0;
+  const int bm = choose_cfg(a.M, a.Cout, a.Cin, &bn);
+  if (bm == 256 && bn == 128 && k64) return launch<256, 128, 64, 4, 2>(a, stream);
+  if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
+  if (bm == 128 && bn == 64) return k64 ? launch<128, 64, 64, 2, 2>(a, stream) : launch<128, 64, 32, 2, 2>(a, stream);
+  if (bm == 64 && bn == 64) return k64 ? launch<64, 64, 64, 2, 2>(a, stream) : launch<64, 64, 32, 2, 2>(a, stream);
+  if (bm == 128 && bn == 32) return k64 ? launch<128, 32, 64, 4, 1>(a, stream) : launch<128, 32, 32, 4, 1>(a, stream);
+  return YV1_ERR_UNSUPPORTED;
 }
 
 // NCHW fp32 image -> zero-padded NHWC4 bf16 [N][H+6][W+6][4] (pad 3 each side, channel 3 = 0).
@@ -372,6 +447,7 @@ extern "C" int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, 
   a.OH = a.P; a.OW = a.Q; a.ldy = ldy; a.os = 1; a.accumulate = 0;
   a.M = N * a.P * a.Q;
   a.ldx = 4;
+  a.dbg = 0;
   if (Cout % 64) return YV1_ERR_UNSUPPORTED;
   // the last tap row of the last pixel reads up to element ((IH-1)*IW + 2*(Q-1))*4 + 31 < IH*IW*4
   return launch<128, 64, 32, 2, 2>(a, stream);
@@ -407,14 +483,10 @@ extern "C" int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* 
 }
 
 extern "C" int yv1_conv2d_stats_rows(int M, int Cout, int Cin) {
-  // number of partial rows the forward kernel writes for this shape (mirrors dispatch())
-  const long long tiles128 = (long long)((M + 127) / 128) * ((Cout + 127) / 128);
-  if (Cout % 128 == 0 && tiles128 >= 512) return (M + 127) / 128;
-  if (Cout % 64 == 0) {
-    const long long tiles = (long long)((M + 127) / 128) * (Cout / 64);
-    return tiles >= 512 ? (M + 127) / 128 : (M + 63) / 64;
-  }
-  return (M + 127) / 128;
+  // number of partial rows the forward kernel writes for this shape (same tile choice as dispatch())
+  int bn = 0;
+  const int bm = choose_cfg(M, Cout, Cin, &bn);
+  return (M + bm - 1) / bm;
 }
 
 extern "C" int yv1_pack_input_nhwc4(const float* x_nchw, void* y, int N, int H, int W, hipStream_t stream) {

@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(256) k_bn_stats(StatsArgs a, int TX) {
       for (int k = 0; k < 8; ++k) acc[j][v][k] = 0.f;
   const long long p0 = (long long)blockIdx.x * a.pix_per_block;
   const long long p1 = min(a.npix, p0 + a.pix_per_block);
+#pragma unroll 2
   for (long long p = p0 + ty; p < p1; p += TY) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -248,6 +249,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
   }
   const long long p0 = (long long)blockIdx.x * a.pix_per_block;
   const long long p1 = min(a.npix, p0 + a.pix_per_block);
+#pragma unroll 2
   for (long long p = p0 + ty; p < p1; p += TY) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
