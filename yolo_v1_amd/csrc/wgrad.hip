@@ -17,6 +17,7 @@
 // The result layout [Cout][taps][Cin] fp32 is exactly the channels_last storage of the OIHW
 // parameter's .grad, so the optimizer consumes it without a layout pass.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -35,9 +36,9 @@ struct WgradArgs {
   int M;                        // N*P*Q
   int splitK, steps_per_split;  // K-steps (of 32 pixels) per split
   int CT, KT;                   // cin tiles, cout tiles
+  int dbg;                      // tuning only: bit0 skip in-loop loads, bit1 skip MFMA block
 };
 
-constexpr int KP = 32;  // pixels per K-step
 
 __device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
   typedef __attribute__((address_space(3))) short4_ lds_s4;
@@ -45,8 +46,8 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
   return __builtin_bit_cast(bf16x4, v);
 }
 
-template <int BMC, int BNC, int WM, int WN>
-__global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
+template <int BMC, int BNC, int WM, int WN, int KP>
+__global__ void __launch_bounds__(256, 2) k_wgrad(WgradArgs a) {
   constexpr int PA = BMC * 2 + 64, PB = BNC * 2 + 64;     // LDS row pitches (bytes)
   constexpr int A_BYTES = KP * PA, B_BYTES = KP * PB;
   constexpr int STAGE = A_BYTES + B_BYTES;
@@ -69,55 +70,65 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
   const int r = tap / a.S, s = tap - r * a.S;
   const int k0 = kt_ * BMC, c0 = ct * BNC;
 
+  // steps_per_split counts KP-pixel steps of THIS instantiation (the host plans with the same KP)
   const int step0 = split * a.steps_per_split;
   const int total_steps = (a.M + KP - 1) / KP;
   const int nsteps = min(a.steps_per_split, total_steps - step0);
 
-  uint4 ra[A_PASSES], rb[B_PASSES];
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 ra[A_PASSES], rb[B_PASSES];
   const int PQ = a.P * a.Q;
+  constexpr int A_ROWSTEP = 256 / ACH, B_ROWSTEP = 256 / BCH;   // rows covered per pass
+  const int a_row = tid / ACH, a_cc = tid % ACH;
+  const int b_row = tid / BCH, b_cc = tid % BCH;
+  const bool a_cok = k0 + a_cc * 8 < a.Cout;
+  // x-operand pixel state per pass, advanced incrementally by KP pixels per K-step (no divisions in the loop)
+  int xn[B_PASSES], xp[B_PASSES], xq[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int m = step0 * KP + b_row + i * B_ROWSTEP;
+    const int n = m / PQ, rem = m - n * PQ;
+    xn[i] = n; xp[i] = rem / a.Q; xq[i] = rem - xp[i] * a.Q;
+  }
+  int ld_m = step0 * KP;               // first pixel of the K-step the loader fetches next
 
-  auto load_tiles = [&](int step) {
-    const int mbase = (step0 + step) * KP;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / ACH, cc = idx - row * ACH;
-      const int m = mbase + row;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (row < KP && m < a.M && k0 + cc * 8 < a.Cout)
-        ra[i] = *reinterpret_cast<const uint4*>(a.DY + (size_t)m * a.lddy + k0 + cc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / BCH, cc = idx - row * BCH;
-      const int m = mbase + row;
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (row < KP && m < a.M) {
-        const int n = m / PQ, rem = m - n * PQ;
-        const int p = rem / a.Q, q = rem - p * a.Q;
-        const int ih = p * a.ah + r * a.bh + a.ch, iw = q * a.aw + s * a.bw + a.cw;
-        if (ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW)
-          rb[i] = *reinterpret_cast<const uint4*>(a.X + ((size_t)(n * a.IH + ih) * a.IW + iw) * a.ldx + c0 + cc * 8);
-      }
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    unsigned char* sa = smem + buf * STAGE;
-    unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / ACH, cc = idx - row * ACH;
-      if (row < KP) *reinterpret_cast<uint4*>(sa + row * PA + cc * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / BCH, cc = idx - row * BCH;
-      if (row < KP) *reinterpret_cast<uint4*>(sb + row * PB + cc * 16) = rb[i];
-    }
-  };
+#define YV1_WG_LOAD()                                                                                            \
+  {                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const int row = a_row + i * A_ROWSTEP;                                                                     \
+      const int m = ld_m + row;                                                                                  \
+      const bool ok = row < KP && m < a.M && a_cok;                                                              \
+      const u32x4 v = *reinterpret_cast<const u32x4*>(a.DY + (ok ? (size_t)m * a.lddy + k0 + a_cc * 8 : (size_t)0)); \
+      const u32x4 z = {0u, 0u, 0u, 0u};                                                                          \
+      ra[i] = ok ? v : z;                                                                                        \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
+      const int row = b_row + i * B_ROWSTEP;                                                                     \
+      const int ih = xp[i] * a.ah + r * a.bh + a.ch, iw = xq[i] * a.aw + s * a.bw + a.cw;                        \
+      const bool ok = row < KP && ld_m + row < a.M && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW;              \
+      const size_t off = ok ? ((size_t)(xn[i] * a.IH + ih) * a.IW + iw) * a.ldx + c0 + b_cc * 8 : (size_t)0;     \
+      const u32x4 v = *reinterpret_cast<const u32x4*>(a.X + off);                                                \
+      const u32x4 z = {0u, 0u, 0u, 0u};                                                                          \
+      rb[i] = ok ? v : z;                                                                                        \
+      xq[i] += KP;                                                                                               \
+      while (xq[i] >= a.Q) { xq[i] -= a.Q; ++xp[i]; }                                                            \
+      while (xp[i] >= a.P) { xp[i] -= a.P; ++xn[i]; }                                                            \
+    }                                                                                                            \
+    ld_m += KP;                                                                                                  \
+  }
+#define YV1_WG_STORE(BUF_)                                                                                       \
+  {                                                                                                              \
+    unsigned char* sa_ = smem + (BUF_) * STAGE;                                                                  \
+    unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const int row = a_row + i * A_ROWSTEP;                                                                     \
+      if (row < KP) *reinterpret_cast<u32x4*>(sa_ + row * PA + a_cc * 16) = ra[i];                               \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
+      const int row = b_row + i * B_ROWSTEP;                                                                     \
+      if (row < KP) *reinterpret_cast<u32x4*>(sb_ + row * PB + b_cc * 16) = rb[i];                               \
+    }                                                                                                            \
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -135,16 +146,18 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
   const int chan_off = 16 * (g & 1) + 4 * tp;         // channel offset inside a 32-channel block
 
   if (nsteps > 0) {
-    load_tiles(0);
-    store_tiles(0);
+    YV1_WG_LOAD();
+    YV1_WG_STORE(0);
   }
   __syncthreads();
 
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1;
-    if (st + 1 < nsteps) load_tiles(st + 1);
+    const bool do_ld = (st + 1 < nsteps) && !(a.dbg & 1);
+    if (do_ld) YV1_WG_LOAD();
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + A_BYTES;
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < KP / 16; ++ks) {
       const int prow = ks * 16 + 8 * h + tq;
@@ -169,7 +182,7 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (st + 1 < nsteps) store_tiles(cur ^ 1);
+    if (do_ld) YV1_WG_STORE(cur ^ 1);
     __syncthreads();
   }
 
@@ -190,27 +203,70 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
     }
 }
 
-__global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long long n, int splitK) {
+// out[i] = sum_s slabs[s][i].  256 threads = 16 float4 columns x 16 split lanes: a lane sums every 16th slab
+// (independent loads in flight), the 16 partial sums are combined through LDS in a fixed order
+// (bitwise reproducible).  Small weights with hundreds of slabs are no longer one serial chain per thread.
+__global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long long n,
+                                                      int splitK) {
+  __shared__ float4 red[16][16];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const long long n4 = n >> 2;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    float4 s = reinterpret_cast<const float4*>(slabs)[i];
-    for (int k = 1; k < splitK; ++k) {
+  const long long i = (long long)blockIdx.x * 16 + col;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    int k = sl;
+    for (; k + 16 < splitK; k += 32) {
+      const float4 v0 = reinterpret_cast<const float4*>(slabs + (size_t)k * n)[i];
+      const float4 v1 = reinterpret_cast<const float4*>(slabs + (size_t)(k + 16) * n)[i];
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+    }
+    for (; k < splitK; k += 16) {
       const float4 v = reinterpret_cast<const float4*>(slabs + (size_t)k * n)[i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    reinterpret_cast<float4*>(out)[i] = s;
+  }
+  red[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    float4 t = red[0][col];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const float4 v = red[j][col];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = t;
   }
 }
 
-template <int BMC, int BNC, int WM, int WN>
+template <int BMC, int BNC, int WM, int WN, int KP>
 int launch(WgradArgs& a, int nblocks, hipStream_t stream) {
   constexpr int STAGE = KP * (BMC * 2 + 64) + KP * (BNC * 2 + 64);
-  hipLaunchKernelGGL((k_wgrad<BMC, BNC, WM, WN>), dim3(nblocks), dim3(256), 2 * STAGE, stream, a);
+  if (2 * STAGE > 64 * 1024) {
+    static bool once = false;
+    if (!once) {
+      YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad<BMC, BNC, WM, WN, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+      once = true;
+    }
+  }
+  hipLaunchKernelGGL((k_wgrad<BMC, BNC, WM, WN, KP>), dim3(nblocks), dim3(256), 2 * STAGE, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
 
-struct Plan { int bmc, bnc, KT, CT, splitK, steps; };
+struct Plan { int bmc, bnc, kp, KT, CT, splitK, steps; };
+
+int wgrad_want_blocks() {
+  static int w = 0;
+  if (!w) { const char* e = getenv("YV1_WGRAD_BLOCKS"); w = e ? atoi(e) : 768; if (w < 64) w = 768; }
+  return w;
+}
+
+int wgrad_kp() {
+  static int kp = 0;
+  if (!kp) { const char* e = getenv("YV1_WGRAD_KP"); kp = e ? atoi(e) : 32; if (kp != 32 && kp != 64 && kp != 128) kp = 32; }
+  return kp;
+}
 
 Plan make_plan(int M, int Cin, int Cout, int taps) {
   Plan p;
@@ -220,16 +276,40 @@ Plan make_plan(int M, int Cin, int Cout, int taps) {
   else { p.bmc = 128; p.bnc = 32; }
   p.KT = (Cout + p.bmc - 1) / p.bmc;
   p.CT = (Cin + p.bnc - 1) / p.bnc;
+  p.kp = wgrad_kp();
+  if (p.kp == 128 && p.bmc == 128 && p.bnc == 128) p.kp = 64;      // LDS budget
   const int tiles = p.KT * p.CT * taps;
-  const int total_steps = (M + KP - 1) / KP;
-  int want = (768 + tiles - 1) / tiles;             // aim for ~3 workgroups per CU
-  int maxsplit = total_steps / 16;                  // at least 16 K-steps (512 pixels) per split
+  const int total_steps = (M + p.kp - 1) / p.kp;
+  int want = (wgrad_want_blocks() + tiles - 1) / tiles;   // aim for 2-3 workgroups per CU
+  int maxsplit = total_steps / (512 / p.kp);        // at least 512 pixels per split
   if (maxsplit < 1) maxsplit = 1;
   if (want > maxsplit) want = maxsplit;
   if (want < 1) want = 1;
   p.steps = (total_steps + want - 1) / want;
   p.splitK = (total_steps + p.steps - 1) / p.steps;
   return p;
+}
+
+template <int KP>
+int run_plan_kp(const Plan& p, WgradArgs& a, int nblocks, hipStream_t stream) {
+  if (p.bmc == 128 && p.bnc == 128) {
+    if constexpr (KP <= 64) return launch<128, 128, 2, 2, KP>(a, nblocks, stream);
+    else return YV1_ERR_UNSUPPORTED;
+  }
+  if (p.bmc == 64) return launch<64, 64, 2, 2, KP>(a, nblocks, stream);
+  if (p.bmc == 32) return launch<32, 128, 1, 4, KP>(a, nblocks, stream);
+  return launch<128, 32, 4, 1, KP>(a, nblocks, stream);
+}
+
+int run_plan(const Plan& p, WgradArgs& a, int nblocks, hipStream_t stream) {
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("YV1_WGRAD_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
+  }
+  if (p.kp == 32) return run_plan_kp<32>(p, a, nblocks, stream);
+  if (p.kp == 128) return run_plan_kp<128>(p, a, nblocks, stream);
+  return run_plan_kp<64>(p, a, nblocks, stream);
 }
 
 }  // namespace
@@ -259,16 +339,11 @@ extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
   a.splitK = p.splitK; a.steps_per_split = p.steps; a.CT = p.CT; a.KT = p.KT;
   a.OUT = p.splitK > 1 ? (float*)workspace : dw;
   const int nblocks = p.splitK * p.KT * p.CT * k * k;
-  int rc;
-  if (p.bmc == 128 && p.bnc == 128) rc = launch<128, 128, 2, 2>(a, nblocks, stream);
-  else if (p.bmc == 64) rc = launch<64, 64, 2, 2>(a, nblocks, stream);
-  else if (p.bmc == 32) rc = launch<32, 128, 1, 4>(a, nblocks, stream);
-  else rc = launch<128, 32, 4, 1>(a, nblocks, stream);
+  int rc = run_plan(p, a, nblocks, stream);
   if (rc) return rc;
   if (p.splitK > 1) {
     const long long n = (long long)Cout * k * k * Cin;
-    int blocks = (int)((n / 4 + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
+    const int blocks = (int)((n / 4 + 15) / 16);
     hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, p.splitK);
     YV1_LAUNCH_CHECK();
   }
@@ -298,11 +373,11 @@ extern "C" int yv1_conv2d_stem_wgrad_bf16(const void* xp, const void* dy, float*
   a.splitK = p.splitK; a.steps_per_split = p.steps; a.CT = p.CT; a.KT = p.KT;
   a.OUT = p.splitK > 1 ? (float*)workspace : dw;
   const int nblocks = p.splitK * p.KT * p.CT * 7;
-  int rc = launch<128, 32, 4, 1>(a, nblocks, stream);
+  int rc = run_plan(p, a, nblocks, stream);
   if (rc) return rc;
   if (p.splitK > 1) {
     const long long n = (long long)Cout * 7 * 32;
-    int blocks = (int)((n / 4 + 255) / 256);
+    const int blocks = (int)((n / 4 + 15) / 16);
     hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, p.splitK);
     YV1_LAUNCH_CHECK();
   }

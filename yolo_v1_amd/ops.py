@@ -180,8 +180,8 @@ class BNState:
 
 
 def _shrink_partials(part, rows, W, dev):
-    """Two-stage row reduction when there are many partial rows."""
-    if rows <= 48:
+    """Pre-reduction of very long partial tables (the finalize kernels sum up to ~2k rows themselves)."""
+    if rows <= 2048:
         return part, rows
     RB = (rows + 31) // 32
     r2 = (rows + RB - 1) // RB
