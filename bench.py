@@ -26,11 +26,17 @@ TRAIN_GFLOP_PER_IMG = {("resnet", 7): 103.25, ("resnet", 14): 97.22, ("densenet"
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(steps=5, warmup=2):
+def cpu_baseline(steps=60, warmup=3):
     """BASELINE.json configs[0]: ResNet-50 448x448 S=7 batch 2 fp32 on the host cores, through the CPU
     oracle (our restatement of the reference modules; the reference itself never travels)."""
     from oracle import train_step as ots
-    torch.set_num_threads(os.cpu_count())
+    # the GPU box gives a 1-GPU job a share of ~16 host cores; os.cpu_count() reports the whole machine, and
+    # oversubscribing OpenMP threads on a quota stalls for minutes
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, avail)))
     P = ots.make_state("resnet", 7, seed=0)
     images, target = ots.synthetic_batch(2, 7)
     times = []

@@ -171,12 +171,12 @@ __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
 // Thread layout: TX threads across 16-B channel chunks (TX = pow2 <= CH), TY = 256/TX pixel lanes;
 // a thread owns chunk columns tx and tx+TX (CH < 2*TX).  Per-block partial rows go to
 // out[blockIdx.x][NV][C].
-template <int NV>
-__device__ __forceinline__ void block_column_reduce(float (&acc)[2][NV][8], int tx, int ty, int TX, int TY, int CH, int C,
+template <int NV, int NCOL>
+__device__ __forceinline__ void block_column_reduce(float (&acc)[NCOL][NV][8], int tx, int ty, int TX, int TY, int CH, int C,
                                                     float* __restrict__ out_row) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [TY][NV][C]
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NCOL; ++j) {
     const int col = tx + j * TX;
     if (col < CH) {
 #pragma unroll
@@ -197,12 +197,13 @@ struct StatsArgs {
   const bf16_t* y; int ldy; long long npix; int C; int pix_per_block; float* part;  // [blocks][2][C]
 };
 
+template <int NCOL>
 __global__ void __launch_bounds__(256) k_bn_stats(StatsArgs a, int TX) {
   const int CH = a.C >> 3, TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  float acc[2][2][8];
+  float acc[NCOL][2][8];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NCOL; ++j)
 #pragma unroll
     for (int v = 0; v < 2; ++v)
 #pragma unroll
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(256) k_bn_stats(StatsArgs a, int TX) {
 #pragma unroll 2
   for (long long p = p0 + ty; p < p1; p += TY) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NCOL; ++j) {
       const int col = tx + j * TX;
       if (col < CH) {
         float f[8];
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(256) k_bn_stats(StatsArgs a, int TX) {
       }
     }
   }
-  block_column_reduce<2>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
+  block_column_reduce<2, NCOL>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
 }
 
 struct BwdArgs {
@@ -256,13 +257,14 @@ __device__ __forceinline__ void masked_grad(const BwdArgs& a, long long p, int c
   }
 }
 
+template <int NCOL>
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
   const int CH = a.C >> 3, TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  float acc[2][2][8];
-  float mu[2][8], is[2][8];
+  float acc[NCOL][2][8];
+  float mu[NCOL][8], is[NCOL][8];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NCOL; ++j) {
     const int col = tx + j * TX;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { acc[j][0][k] = 0.f; acc[j][1][k] = 0.f; mu[j][k] = 0.f; is[j][k] = 0.f; }
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
 #pragma unroll 2
   for (long long p = p0 + ty; p < p1; p += TY) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NCOL; ++j) {
       const int col = tx + j * TX;
       if (col < CH) {
         float yv[8], g[8];
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
       }
     }
   }
-  block_column_reduce<2>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
+  block_column_reduce<2, NCOL>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
 }
 
 // dgamma = sum dyh*xhat, dbeta = sum dyh;  dy = k1*dyh - k2 - xhat*k3 with
@@ -702,7 +704,8 @@ extern "C" int yv1_bn_stats(const void* y, int ldy, long long npix, int C, float
   if (rc) return rc;
   if (ldy % 8) return YV1_ERR_UNSUPPORTED;
   StatsArgs a; a.y = (const bf16_t*)y; a.ldy = ldy; a.npix = npix; a.C = C; a.pix_per_block = ppb; a.part = partials;
-  hipLaunchKernelGGL(k_bn_stats, dim3(blocks), dim3(256), lds, stream, a, TX);
+  if (C / 8 > TX) hipLaunchKernelGGL(k_bn_stats<2>, dim3(blocks), dim3(256), lds, stream, a, TX);
+  else hipLaunchKernelGGL(k_bn_stats<1>, dim3(blocks), dim3(256), lds, stream, a, TX);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
@@ -720,7 +723,8 @@ extern "C" int yv1_bn_bwd_reduce(const void* dz, int lddz, const void* z, int ld
   a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
   a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.npix = npix; a.C = C; a.pix_per_block = ppb;
   a.mask_mode = mask_mode; a.part = partials;
-  hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(blocks), dim3(256), lds, stream, a, TX);
+  if (C / 8 > TX) hipLaunchKernelGGL(k_bn_bwd_reduce<2>, dim3(blocks), dim3(256), lds, stream, a, TX);
+  else hipLaunchKernelGGL(k_bn_bwd_reduce<1>, dim3(blocks), dim3(256), lds, stream, a, TX);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
