@@ -74,8 +74,9 @@ def main():
     torch.manual_seed(0)
     net, loss_layer, opt = build(args.backbone, args.S, 2, 20, args.batch, device, quiet=True,
                                  fused_optimizer=bool(args.fused_sgd))
-    sync = ydist.GradSync(net) if world > 1 else None
-    if world > 1:                                # same initial weights on every rank
+    use_dist = torch.distributed.is_initialized()
+    sync = ydist.GradSync(net) if use_dist else None
+    if use_dist:                                 # same initial weights on every rank
         for p in net.state_dict().values():
             torch.distributed.broadcast(p, 0)
     images, target = synthetic_batch(args.batch, args.S, seed=1234 + rank, device=device)
@@ -102,7 +103,7 @@ def main():
     for _ in range(max(0, args.warmup - (graphed.steps_done if graphed else 0))):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -112,12 +113,12 @@ def main():
         loss = step()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)               # HIP events on the stream every kernel of the step is launched on
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -150,7 +151,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

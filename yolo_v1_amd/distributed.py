@@ -31,7 +31,8 @@ def init_from_env(backend=None):
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("YV1_FORCE_DIST") == "1"      # rehearse the multi-rank code path with a group of one
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {"device_id": device} if use_cuda else {}
@@ -71,7 +72,9 @@ class GradSync:
         if not self.pending:
             return
         flat = torch.cat([_flat_memory_view(g) for _, g in self.pending])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+        work = None
+        if dist.is_initialized():
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.inflight.append((work, flat, [p for p, _ in self.pending],
                               [(g.numel(), tuple(g.shape), tuple(g.stride())) for _, g in self.pending]))
         self.pending, self.pending_bytes = [], 0
