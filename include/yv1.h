@@ -85,13 +85,14 @@ int yv1_bn_finalize(const float* partials, int rows, int C, int ld_partials, flo
                     float* invstd, float* scale, float* shift, yv1_stream_t stream);
 int yv1_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, yv1_stream_t stream);
-/* z = relu?(scale*y + shift [+ residual | + res_scale*residual + res_shift]) */
+/* z = relu?(scale*y + shift [+ residual | + res_scale*residual + res_shift]); relu_mask (nullable): uint8
+ * [npix][C/8], bit k of byte j = (channel 8j+k > 0), so the backward need not re-read z for its sign */
 int yv1_bn_apply(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
                  const float* shift, const float* res_scale, const float* res_shift, long long npix, int C, int relu,
-                 yv1_stream_t stream);
+                 void* relu_mask, yv1_stream_t stream);
 int yv1_bn_reduce_rows(long long npix, int C);
 int yv1_bn_stats(const void* y, int ldy, long long npix, int C, float* partials, yv1_stream_t stream);
-/* mask_mode: 0 none, 1 ReLU mask from z > 0, 2 ReLU mask from scale*y+shift > 0 */
+/* mask_mode: 0 none, 1 ReLU mask from z > 0, 2 from scale*y+shift > 0, 3 z is yv1_bn_apply's relu_mask (ldz = C/8 bytes) */
 int yv1_bn_bwd_reduce(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
                       const float* invstd, const float* scale, const float* shift, long long npix, int C, int mask_mode,
                       float* partials, yv1_stream_t stream);

@@ -147,7 +147,7 @@ def test_bn_forward_backward(C, N, H):
     ya, ra = nhwc_act(y), nhwc_act(res)
     st = ops.bn_finalize(ops.bn_stats(ya), ya.npix, bn)
     za = ops.new_act(N, H, H, C, DEV)
-    ops.bn_apply(ya, st, za, relu=True, residual=ra)
+    rmask = ops.bn_apply(ya, st, za, relu=True, residual=ra, want_mask=True)
     yr = y.clone().requires_grad_(True)
     zr = F.relu(ref_bn(yr) + res)
     torch.cuda.synchronize()
@@ -165,6 +165,11 @@ def test_bn_forward_backward(C, N, H):
     np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.bias.grad.abs().max()))
     mask = (zr.detach() > 0).float()
     close(to_nchw(dra), gz * mask, rtol=1e-2, scale_atol=1e-2)
+    # the 1-bit mask written by bn_apply gives bit-identical results to reading z back (mode 3 vs mode 1)
+    dyc, drc = ops.new_act(N, H, H, C, DEV), ops.new_act(N, H, H, C, DEV)
+    dg3, db3 = ops.bn_backward(nhwc_act(gz), ya, st, bn, dyc, 3, z=rmask, dres=drc)
+    torch.cuda.synchronize()
+    assert torch.equal(dyc.t, dya.t) and torch.equal(drc.t, dra.t) and torch.equal(dg3, dg) and torch.equal(db3, db)
     # mode 2 (mask from scale*y+shift) without residual, accumulate into an existing gradient
     yr2 = y.clone().requires_grad_(True)
     ref_bn.zero_grad()

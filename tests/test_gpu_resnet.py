@@ -182,7 +182,7 @@ def test_resnet50_every_layer_teacher_forced():
     chk("stem bn", nchw(z0), F.relu(bnf(nchw(y0), "bn1")))
     chk("maxpool", nchw(rec["blocks"][0][1]), F.max_pool2d(nchw(z0), 3, 2, 1))
     names = ["%s.%d" % (st, i) for st in net._stage_names for i in range(len(getattr(net, st)))]
-    for name, (blk, xin, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out) in zip(names, rec["blocks"]):
+    for name, (blk, xin, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, _m) in zip(names, rec["blocks"]):
         xi = nchw(xin)
         chk(name + " y1", nchw(y1), F.conv2d(xi, bfw(name + ".conv1.weight")))
         chk(name + " z1", nchw(z1), F.relu(bnf(nchw(y1), name + ".bn1")))

@@ -40,7 +40,7 @@ names = []
 for st in net._stage_names:
     for i in range(len(getattr(net, st))):
         names.append("%s.%d" % (st, i))
-for name, (blk, xin, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out) in zip(names, rec["blocks"]):
+for name, (blk, xin, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, _m) in zip(names, rec["blocks"]):
     xi = nchw(xin)
     w1 = P2[name + ".conv1.weight"].to(torch.bfloat16).float()
     rep(name + " y1", nchw(y1), F.conv2d(xi, w1))

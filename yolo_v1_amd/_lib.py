@@ -46,7 +46,7 @@ SIGNATURES = {
     "yv1_reduce_rows": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "yv1_bn_finalize": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yv1_bn_eval_coeffs": (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
-    "yv1_bn_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p]),
+    "yv1_bn_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p]),
     "yv1_bn_reduce_rows": (c_i, [c_ll, c_i]),
     "yv1_bn_stats": (c_i, [c_p, c_i, c_ll, c_i, c_p, c_p]),
     "yv1_bn_bwd_reduce": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p]),

@@ -123,11 +123,11 @@ class ResNet(HipBackbone):
                 wd = self.cw(blk.downsample[0])
                 yd = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
                 sd = norm(ops.conv_fwd(x, wd, yd, train), yd.npix, blk.downsample[1])
-                ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd)
+                omask = ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd, want_mask=save)
             else:
-                ops.bn_apply(y3, s3, out, relu=True, residual=x)
+                omask = ops.bn_apply(y3, s3, out, relu=True, residual=x, want_mask=save)
             if save:
-                rec["blocks"].append((blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out))
+                rec["blocks"].append((blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask))
             x = out
 
         # head: 1x1 conv -> bn_end -> sigmoid, already NHWC                      (:186-189)
@@ -155,20 +155,20 @@ class ResNet(HipBackbone):
         ops.conv_dgrad(dyh, wh, g)
         self._emit(grads, [self.bn_end.weight, self.bn_end.bias, self.layer6.weight])
 
-        for (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out) in reversed(rec["blocks"]):
+        for (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask) in reversed(rec["blocks"]):
             w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
             g_in = ops.new_act(N, x.H, x.W, x.C, dev)
             dy3 = ops.new_act(N, y3.H, y3.W, y3.C, dev)
             if yd is not None:
                 wd = self.cw(blk.downsample[0])
                 bnd = blk.downsample[1]
-                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 1, z=out)
+                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
                 dyd = ops.new_act(N, yd.H, yd.W, yd.C, dev)
-                grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 1, z=out)
+                grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
                 grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd)
             else:
                 # identity shortcut: the masked gradient is also the shortcut's contribution to g_in
-                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 1, z=out, dres=g_in)
+                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask, dres=g_in)
             grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3)
             dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
             ops.conv_dgrad(dy3, w3, dz2)

@@ -132,6 +132,7 @@ struct ApplyArgs {
   const float* scale; const float* shift;
   const float* rscale; const float* rshift;   // when set, residual is a raw conv output with its own BN
   long long npix; int C; int relu;
+  unsigned char* relu_mask;       // optional [npix][C/8]: bit k of byte j = output channel 8j+k is > 0
 };
 
 __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
@@ -160,6 +161,12 @@ __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
       for (int k = 0; k < 8; ++k) f[k] += r[k];
     }
     if (a.relu) {
+      if (a.relu_mask) {
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m |= (f[k] > 0.f ? 1u : 0u) << k;
+        a.relu_mask[pix * CH + (cc >> 3)] = (unsigned char)m;
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
     }
@@ -232,7 +239,7 @@ struct BwdArgs {
   const bf16_t* y; int ldy;        // BN input (raw conv output)
   const float* mean; const float* invstd; const float* scale; const float* shift;
   long long npix; int C; int pix_per_block;
-  int mask_mode;                   // 0 none, 1 z > 0, 2 scale*y+shift > 0
+  int mask_mode;                   // 0 none, 1 z > 0, 2 scale*y+shift > 0, 3 z is a bit mask [npix][ldz bytes]
   float* part;                     // reduce: [blocks][2][C]  (sum dyh, sum dyh*xhat)
   // apply:
   const float* k1; const float* k2; const float* k3;   // dy = k1*dyh - k2 - xhat*k3 ... see finalize
@@ -248,6 +255,10 @@ __device__ __forceinline__ void masked_grad(const BwdArgs& a, long long p, int c
     unpack8(*reinterpret_cast<const u32x4*>(a.z + p * a.ldz + c8), zv);
 #pragma unroll
     for (int k = 0; k < 8; ++k) g[k] = zv[k] > 0.f ? g[k] : 0.f;
+  } else if (a.mask_mode == 3) {
+    const unsigned m = reinterpret_cast<const unsigned char*>(a.z)[p * a.ldz + (c8 >> 3)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = ((m >> k) & 1u) ? g[k] : 0.f;
   } else if (a.mask_mode == 2) {
     float sc[8], sh[8];
     load8f(a.scale + c8, sc);
@@ -661,25 +672,32 @@ extern "C" int yv1_bn_eval_coeffs(int C, const float* gamma, const float* beta, 
 
 extern "C" int yv1_bn_apply(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
                             const float* shift, const float* res_scale, const float* res_shift, long long npix, int C,
-                            int relu, hipStream_t stream) {
+                            int relu, void* relu_mask, hipStream_t stream) {
   if (!y || !z || !scale || !shift || npix <= 0 || C <= 0) return YV1_ERR_BAD_ARG;
   if (C % 8 || ldy % 8 || ldz % 8 || (residual && ldr % 8)) return YV1_ERR_UNSUPPORTED;
   ApplyArgs a;
   a.y = (const bf16_t*)y; a.ldy = ldy; a.z = (bf16_t*)z; a.ldz = ldz; a.res = (const bf16_t*)residual; a.ldr = ldr;
   a.scale = scale; a.shift = shift; a.rscale = res_scale; a.rshift = res_shift; a.npix = npix; a.C = C; a.relu = relu;
+  a.relu_mask = (unsigned char*)relu_mask;
   hipLaunchKernelGGL(k_bn_apply, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
+}
+
+// pixels per workgroup of the column-parallel reductions: aim for ~2048 workgroups (8 per CU) so small
+// feature maps are not a few long serial chains; at least 4 pixel iterations per thread
+static long long reduce_ppb(long long npix, int TY) {
+  long long p = (npix + 2047) / 2048;
+  p = (p + TY - 1) / TY * TY;
+  if (p < (long long)TY * 4) p = (long long)TY * 4;
+  return p;
 }
 
 // number of partial rows yv1_bn_stats / yv1_bn_bwd_reduce write for npix pixels
 extern "C" int yv1_bn_reduce_rows(long long npix, int C) {
   const int CH = C / 8;
   const int TX = floor_pow2(CH < 256 ? CH : 256), TY = 256 / TX;
-  long long ppb = (long long)TY * 64;                 // 64 pixel iterations per thread
-  long long blocks = (npix + ppb - 1) / ppb;
-  while (blocks > 2048) { ppb *= 2; blocks = (npix + ppb - 1) / ppb; }
-  return (int)blocks;
+  return (int)((npix + reduce_ppb(npix, TY) - 1) / reduce_ppb(npix, TY));
 }
 
 static int reduce_geometry(long long npix, int C, int* TX, int* ppb, int* blocks, size_t* lds) {
@@ -688,10 +706,8 @@ static int reduce_geometry(long long npix, int C, int* TX, int* ppb, int* blocks
   *TX = floor_pow2(CH < 256 ? CH : 256);
   if (CH >= 2 * *TX) return YV1_ERR_UNSUPPORTED;
   const int TY = 256 / *TX;
-  long long p = (long long)TY * 64;
-  long long b = (npix + p - 1) / p;
-  while (b > 2048) { p *= 2; b = (npix + p - 1) / p; }
-  *ppb = (int)p; *blocks = (int)b;
+  const long long p = reduce_ppb(npix, TY);
+  *ppb = (int)p; *blocks = (int)((npix + p - 1) / p);
   *lds = (size_t)TY * 2 * C * sizeof(float);
   return YV1_OK;
 }
@@ -714,11 +730,11 @@ extern "C" int yv1_bn_bwd_reduce(const void* dz, int lddz, const void* z, int ld
                                  const float* invstd, const float* scale, const float* shift, long long npix, int C,
                                  int mask_mode, float* partials, hipStream_t stream) {
   if (!dz || !y || !mean || !invstd || !partials || npix <= 0) return YV1_ERR_BAD_ARG;
-  if ((mask_mode == 1 && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
+  if (((mask_mode == 1 || mask_mode == 3) && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
   int TX, ppb, blocks; size_t lds;
   int rc = reduce_geometry(npix, C, &TX, &ppb, &blocks, &lds);
   if (rc) return rc;
-  if (lddz % 8 || ldy % 8 || (z && ldz % 8)) return YV1_ERR_UNSUPPORTED;
+  if (lddz % 8 || ldy % 8 || (z && mask_mode == 1 && ldz % 8)) return YV1_ERR_UNSUPPORTED;
   BwdArgs a = {};
   a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
   a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.npix = npix; a.C = C; a.pix_per_block = ppb;
@@ -744,8 +760,8 @@ extern "C" int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz
                                 const float* k2, const float* k3, long long npix, int C, int mask_mode, void* dy, int lddy,
                                 void* dres, int lddres, int accumulate, hipStream_t stream) {
   if (!dz || !y || !mean || !invstd || !k1 || !k2 || !k3 || !dy || npix <= 0) return YV1_ERR_BAD_ARG;
-  if ((mask_mode == 1 && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
-  if (C % 8 || lddz % 8 || ldy % 8 || lddy % 8 || (z && ldz % 8) || (dres && lddres % 8)) return YV1_ERR_UNSUPPORTED;
+  if (((mask_mode == 1 || mask_mode == 3) && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
+  if (C % 8 || lddz % 8 || ldy % 8 || lddy % 8 || (z && mask_mode == 1 && ldz % 8) || (dres && lddres % 8)) return YV1_ERR_UNSUPPORTED;
   BwdArgs a = {};
   a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
   a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.npix = npix; a.C = C; a.mask_mode = mask_mode;

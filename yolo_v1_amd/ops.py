@@ -230,17 +230,31 @@ def bn_stats(x):
     return part
 
 
-def bn_apply(y, st, z, relu=True, residual=None, res_state=None):
+class ReluMask:
+    """1 bit per element sign mask written by bn_apply (uint8 [npix][C/8]); stands in for the activation
+    itself in bn_backward(mask_mode=3) -- 16x fewer bytes than re-reading the bf16 output."""
+    __slots__ = ("t", "p", "ld")
+
+    def __init__(self, npix, C, device):
+        self.t = torch.empty((npix, C // 8), dtype=torch.uint8, device=device)
+        self.p = self.t.data_ptr()
+        self.ld = C // 8
+
+
+def bn_apply(y, st, z, relu=True, residual=None, res_state=None, want_mask=False):
     dev = y.t.device
+    mask = ReluMask(y.npix, y.C, dev) if (want_mask and relu) else None
     check(lib().yv1_bn_apply(y.p, y.ld, z.p, z.ld, residual.p if residual is not None else None,
                              residual.ld if residual is not None else 0, ptr(st.scale), ptr(st.shift),
                              ptr(res_state.scale) if res_state is not None else None,
                              ptr(res_state.shift) if res_state is not None else None, y.npix, y.C, 1 if relu else 0,
-                             stream_ptr(dev)), "yv1_bn_apply")
+                             mask.p if mask is not None else None, stream_ptr(dev)), "yv1_bn_apply")
+    return mask
 
 
 def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=False):
-    """BN (+ReLU) backward.  mask_mode 0: no ReLU; 1: mask from ``z`` > 0; 2: mask from scale*y+shift > 0.
+    """BN (+ReLU) backward.  mask_mode 0: no ReLU; 1: mask from ``z`` > 0; 2: mask from scale*y+shift > 0;
+    3: ``z`` is the ReluMask bn_apply wrote.
     Writes dy (grad wrt the raw conv output) and optionally dres (masked dz, the identity-shortcut
     gradient).  Returns (dgamma, dbeta)."""
     dev = y.t.device
