@@ -48,7 +48,10 @@ struct ConvArgs {
   int Cin, Cout;       // K per tap, GEMM N
   int R, S;
   int ah, bh, ch, aw, bw, cw, log2d;
-  int OH, OW, ldy, os; // destination tensor: GEMM pixel (n,p,q) -> (n, p*os, q*os)
+  int OH, OW, ldy, os; // destination tensor: GEMM pixel (n,p,q) -> (n, p*os + oh0, q*os + ow0)
+  int oh0, ow0;
+  int wr0, wrs, ws0, wss, WS;   // weight tap of loop tap (r,s): (wr0 + r*wrs)*WS + (ws0 + s*wss)
+  int Kw;                       // elements per weight row (= all filter taps x Cin)
   int accumulate;
   int M;
   int MT, NT;
@@ -115,11 +118,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_g
       pix_base[i] = -1; ph[i] = 0; qw[i] = 0;
     }
   }
-  const int Ktot = a.R * a.S * a.Cin;
+  const int Ktot = a.Kw;                  // a weight row always holds the full filter, whatever taps this launch walks
   const int cblocks = a.Cin / BK;
   const int nk = a.R * a.S * cblocks;
   const int dmask = (1 << a.log2d) - 1;
-  // weights: K is walked contiguously (tap-major, then channel block) -> one running offset
+  // weights: row base per thread; the tap / channel-block offset is added per load
   // (32-bit element offsets: every tensor here is far below 2^31 elements; keeps the VGPR count down)
   int woff[B_PASSES];
 #pragma unroll
@@ -131,11 +134,13 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_g
   // The loader runs one K-step ahead of the MFMA block.  Its tap state (source offset of each row
   // for the current filter tap, or "padding") is recomputed only when the tap changes, not per step.
   int ld_r = 0, ld_s = 0, ld_cb = 0;
+  int wtap_off = 0;                    // element offset of the current tap inside a weight row
   int aoff[A_PASSES];                  // element offset of the tapped pixel + chunk column; 0 when the tap is padding
   unsigned avalid = 0;                 // bit i: row i of this thread reads real data for the current tap
 #define YV1_SET_TAP()                                                                                            \
   {                                                                                                              \
     avalid = 0;                                                                                                  \
+    wtap_off = ((a.wr0 + ld_r * a.wrs) * a.WS + (a.ws0 + ld_s * a.wss)) * a.Cin;                                 \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
       const int hn = ph[i] + ld_r * a.bh, wn_ = qw[i] + ld_s * a.bw;                                             \
       const int ih = hn >> a.log2d, iw = wn_ >> a.log2d;                                                         \
@@ -157,8 +162,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_g
       ra[i] = ok ? v : z;                                                                                        \
     }                                                                                                            \
     _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
-      rb[i] = *reinterpret_cast<const u32x4*>(a.W + woff[i]);                                                    \
-      woff[i] += BK;                                                                                             \
+      rb[i] = *reinterpret_cast<const u32x4*>(a.W + (woff[i] + wtap_off + coff));                                \
     }                                                                                                            \
     if (++ld_cb == cblocks) {                                                                                    \
       ld_cb = 0;                                                                                                 \
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_g
         const int pq = a.P * a.Q;
         const int n = m / pq, rem = m - n * pq;
         const int p = rem / a.Q, q = rem - p * a.Q;
-        off = ((size_t)(n * a.OH + p * a.os) * a.OW + q * a.os) * a.ldy + n0 + cc * 8;
+        off = ((size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0) * a.ldy + n0 + cc * 8;
       }
       uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
       if (a.accumulate) {
@@ -429,6 +433,7 @@ extern "C" int yv1_conv2d_fwd_nhwc_bf16(const void* x, const void* w, void* y, i
   a.Cin = Cin; a.Cout = Cout; a.R = k; a.S = k;
   a.ah = stride; a.bh = 1; a.ch = -pad; a.aw = stride; a.bw = 1; a.cw = -pad; a.log2d = 0;
   a.OH = a.P; a.OW = a.Q; a.ldy = ldy; a.os = 1; a.accumulate = 0;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = k; a.Kw = k * k * Cin;
   a.M = N * a.P * a.Q;
   return dispatch(a, stream);
 }
@@ -445,6 +450,7 @@ extern "C" int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, 
   a.Cin = 32; a.Cout = Cout; a.R = 7; a.S = 1;
   a.ah = 2; a.bh = 1; a.ch = 0; a.aw = 2; a.bw = 0; a.cw = 0; a.log2d = 0;
   a.OH = a.P; a.OW = a.Q; a.ldy = ldy; a.os = 1; a.accumulate = 0;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = 1; a.wss = 0; a.WS = 1; a.Kw = 7 * 32;
   a.M = N * a.P * a.Q;
   a.ldx = 4;
   a.dbg = 0;
@@ -469,15 +475,35 @@ extern "C" int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* 
   a.N = N; a.IH = OH; a.IW = OW; a.ldx = lddy;
   a.Cin = Cout; a.Cout = Cin; a.R = k; a.S = k;
   a.OH = IH; a.OW = IW; a.ldy = lddx; a.accumulate = accumulate;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = k; a.Kw = k * k * Cout;
   if (k == 1 && pad == 0) {
     // GEMM over the dy pixels, scattered to (h*stride, w*stride)
     a.P = OH; a.Q = OW; a.os = stride;
     a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
-  } else {
-    // GEMM over the dx pixels; tap (r,s) reads dy at ((h + pad - r)/stride, (w + pad - s)/stride)
-    a.P = IH; a.Q = IW; a.os = 1;
-    a.ah = 1; a.bh = -1; a.ch = pad; a.aw = 1; a.bw = -1; a.cw = pad; a.log2d = (stride == 2) ? 1 : 0;
+    a.M = N * a.P * a.Q;
+    return dispatch(a, stream);
   }
+  if (stride == 2 && k == 3 && pad == 1 && !(IH & 1) && !(IW & 1)) {
+    // Output-parity decomposition: dx[2p+ph, 2q+pw] only receives the filter taps r with (ph + 1 - r) even.
+    //   ph == 0: r = 1,      dy row p              ph == 1: r = 0 -> dy row p+1 ; r = 2 -> dy row p
+    // Four launches, each a dense small convolution over the (IH/2 x IW/2) pixels of its class: no zero taps
+    // are multiplied (the single generic launch below spends 3/4 of its MFMA work on them).
+    a.P = IH / 2; a.Q = IW / 2; a.os = 2; a.log2d = 0;
+    a.M = N * a.P * a.Q;
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) {
+        a.oh0 = ph; a.ow0 = pw;
+        a.R = ph ? 2 : 1; a.S = pw ? 2 : 1;
+        a.ah = 1; a.bh = ph ? -1 : 0; a.ch = ph ? 1 : 0; a.wr0 = ph ? 0 : 1; a.wrs = ph ? 2 : 0;
+        a.aw = 1; a.bw = pw ? -1 : 0; a.cw = pw ? 1 : 0; a.ws0 = pw ? 0 : 1; a.wss = pw ? 2 : 0;
+        const int rc = dispatch(a, stream);
+        if (rc) return rc;
+      }
+    return YV1_OK;
+  }
+  // generic: GEMM over the dx pixels; tap (r,s) reads dy at ((h + pad - r)/stride, (w + pad - s)/stride)
+  a.P = IH; a.Q = IW; a.os = 1;
+  a.ah = 1; a.bh = -1; a.ch = pad; a.aw = 1; a.bw = -1; a.cw = pad; a.log2d = (stride == 2) ? 1 : 0;
   a.M = N * a.P * a.Q;
   return dispatch(a, stream);
 }

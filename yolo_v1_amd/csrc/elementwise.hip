@@ -15,6 +15,7 @@
 // Backward:  yv1_bn_bwd_reduce (sum dyh, sum dyh*xhat, relu mask recomputed from z or from
 // scale*y+shift) -> yv1_bn_bwd_finalize (dgamma, dbeta, coefficients) -> yv1_bn_bwd_apply.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -687,7 +688,8 @@ extern "C" int yv1_bn_apply(const void* y, int ldy, void* z, int ldz, const void
 // pixels per workgroup of the column-parallel reductions: aim for ~2048 workgroups (8 per CU) so small
 // feature maps are not a few long serial chains; at least 4 pixel iterations per thread
 static long long reduce_ppb(long long npix, int TY) {
-  long long p = (npix + 2047) / 2048;
+  static const long long target = [] { const char* e = getenv("YV1_BN_BLOCKS"); long long v = e ? atoll(e) : 1024; return v < 64 ? 1024 : v; }();
+  long long p = (npix + target - 1) / target;
   p = (p + TY - 1) / TY * TY;
   if (p < (long long)TY * 4) p = (long long)TY * 4;
   return p;
