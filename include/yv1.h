@@ -121,6 +121,11 @@ int yv1_head_sigmoid_bwd(const float* dout, const float* out, const void* y, int
 /* ---- weight re-layout (fp32 OIHW parameter, any strides -> bf16 kernel layouts) ------------------------------ */
 int yv1_prep_weights(const float* w, long long so, long long si, long long sh, long long sw, int O, int I, int KH, int KW,
                      int Opad, int Ipad, void* dst_fwd, void* dst_t, yv1_stream_t stream);
+int yv1_prep_weights_max_tensors(void);
+/* the same for `count` weights in ONE launch; every array is a HOST array (strides4 = 4 strides per weight) */
+int yv1_prep_weights_multi(const float* const* w, const long long* strides4, const int* O, const int* I, const int* K,
+                           const int* Opad, const int* Ipad, void* const* dst_fwd, void* const* dst_t, int count,
+                           yv1_stream_t stream);
 int yv1_prep_stem_weights(const float* w, long long so, long long si, long long sh, long long sw, int O, void* dst,
                           yv1_stream_t stream);
 int yv1_unpack_stem_grad(const float* g, float* dw, long long so, long long si, long long sh, long long sw, int O,

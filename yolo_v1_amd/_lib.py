@@ -61,6 +61,8 @@ SIGNATURES = {
     "yv1_head_sigmoid_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_ll, c_i, c_p]),
     "yv1_head_sigmoid_bwd": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_ll, c_i, c_p]),
     "yv1_prep_weights": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "yv1_prep_weights_max_tensors": (c_i, []),
+    "yv1_prep_weights_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "yv1_prep_stem_weights": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p, c_p]),
     "yv1_unpack_stem_grad": (c_i, [c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p]),
     # optim.hip

@@ -86,6 +86,7 @@ class DenseNet(HipBackbone):
         if H % 64 or W % 64:
             raise _lib.Yv1Error("input height/width must be multiples of 64, got %dx%d" % (H, W))
         F = self.features
+        self.refresh_all_weights()
         bns = []
 
         def norm(stats, count, bn, C=None):

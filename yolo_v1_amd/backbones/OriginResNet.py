@@ -83,6 +83,7 @@ class ResNet(HipBackbone):
         N, _, H, W = images.shape
         if H % 64 or W % 64:
             raise _lib.Yv1Error("input height/width must be multiples of 64, got %dx%d" % (H, W))
+        self.refresh_all_weights()
         bns = []
 
         def norm(stats, count, bn, C=None):

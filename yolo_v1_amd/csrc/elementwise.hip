@@ -629,6 +629,44 @@ __global__ void k_unpack_stem_grad(const float* __restrict__ g, float* __restric
   }
 }
 
+// ---- multi-tensor weight prep: one launch re-lays-out up to PREP_MAX convolution weights
+constexpr int PREP_MAX = 40;
+struct PrepTable {
+  const float* w[PREP_MAX];
+  bf16_t* dst_fwd[PREP_MAX];
+  bf16_t* dst_t[PREP_MAX];
+  long long so[PREP_MAX], si[PREP_MAX], sh[PREP_MAX], sw[PREP_MAX];
+  int O[PREP_MAX], I[PREP_MAX], K[PREP_MAX], Opad[PREP_MAX], Ipad[PREP_MAX];
+  int first_block[PREP_MAX + 1];
+  int count;
+};
+constexpr int PREP_ELEMS_PER_BLOCK = 256 * 8;
+
+__global__ void __launch_bounds__(256) k_prep_weights_multi(PrepTable t) {
+  int ti = 0;
+  while (ti + 1 < t.count && (int)blockIdx.x >= t.first_block[ti + 1]) ++ti;
+  const int O = t.O[ti], I = t.I[ti], KW = t.K[ti], taps = KW * KW, Opad = t.Opad[ti], Ipad = t.Ipad[ti];
+  const long long total = (long long)Opad * taps * Ipad;
+  const long long base = (long long)(blockIdx.x - t.first_block[ti]) * PREP_ELEMS_PER_BLOCK;
+  const float* __restrict__ w = t.w[ti];
+  bf16_t* __restrict__ df = t.dst_fwd[ti];
+  bf16_t* __restrict__ dt = t.dst_t[ti];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const long long idx = base + it * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int i = (int)(idx % Ipad);
+    const long long q = idx / Ipad;
+    const int tap = (int)(q % taps);
+    const int o = (int)(q / taps);
+    float v = 0.f;
+    if (o < O && i < I) v = w[o * t.so[ti] + i * t.si[ti] + (tap / KW) * t.sh[ti] + (tap % KW) * t.sw[ti]];
+    const bf16_t b = f32_to_bf16(v);
+    df[idx] = b;
+    if (dt) dt[((size_t)i * taps + tap) * Opad + o] = b;
+  }
+}
+
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 int ew_blocks(long long total) { long long b = (total + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
 
@@ -842,6 +880,33 @@ extern "C" int yv1_prep_weights(const float* w, long long so, long long si, long
   const long long total = (long long)Opad * KH * KW * Ipad;
   hipLaunchKernelGGL(k_prep_weights, dim3(ew_blocks(total)), dim3(256), 0, stream, w, so, si, sh, sw, O, I, KH, KW, Opad, Ipad,
                      (bf16_t*)dst_fwd, (bf16_t*)dst_t);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_prep_weights_max_tensors(void) { return PREP_MAX; }
+
+// Same as yv1_prep_weights for `count` (<= yv1_prep_weights_max_tensors()) square-kernel weights in ONE launch.
+// All arrays are HOST arrays; dst_t[i] may be NULL.
+extern "C" int yv1_prep_weights_multi(const float* const* w, const long long* strides4, const int* O, const int* I, const int* K,
+                                      const int* Opad, const int* Ipad, void* const* dst_fwd, void* const* dst_t, int count,
+                                      hipStream_t stream) {
+  if (!w || !strides4 || !O || !I || !K || !Opad || !Ipad || !dst_fwd || !dst_t || count <= 0 || count > PREP_MAX)
+    return YV1_ERR_BAD_ARG;
+  PrepTable t;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!w[i] || !dst_fwd[i] || O[i] <= 0 || I[i] <= 0 || K[i] <= 0 || Opad[i] < O[i] || Ipad[i] < I[i]) return YV1_ERR_BAD_ARG;
+    t.w[i] = w[i]; t.dst_fwd[i] = (bf16_t*)dst_fwd[i]; t.dst_t[i] = (bf16_t*)dst_t[i];
+    t.so[i] = strides4[4 * i]; t.si[i] = strides4[4 * i + 1]; t.sh[i] = strides4[4 * i + 2]; t.sw[i] = strides4[4 * i + 3];
+    t.O[i] = O[i]; t.I[i] = I[i]; t.K[i] = K[i]; t.Opad[i] = Opad[i]; t.Ipad[i] = Ipad[i];
+    t.first_block[i] = blocks;
+    const long long total = (long long)Opad[i] * K[i] * K[i] * Ipad[i];
+    blocks += (int)((total + PREP_ELEMS_PER_BLOCK - 1) / PREP_ELEMS_PER_BLOCK);
+  }
+  t.first_block[count] = blocks;
+  t.count = count;
+  hipLaunchKernelGGL(k_prep_weights_multi, dim3(blocks), dim3(256), 0, stream, t);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }

@@ -48,7 +48,9 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
 
 template <int BMC, int BNC, int WM, int WN, int KP>
 __global__ void __launch_bounds__(256, 2) k_wgrad(WgradArgs a) {
-  constexpr int PA = BMC * 2 + 64, PB = BNC * 2 + 64;     // LDS row pitches (bytes)
+  // LDS row pitches (bytes): the 4 pixel rows of a transposed read must land on disjoint 16-dword bank quarters,
+  // i.e. pitch = 16 or 48 (mod 64) dwords: 64-B rows need no padding, wider rows get +64 B
+  constexpr int PA = BMC == 32 ? 64 : BMC * 2 + 64, PB = BNC == 32 ? 64 : BNC * 2 + 64;
   constexpr int A_BYTES = KP * PA, B_BYTES = KP * PB;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int ACH = BMC / 8, BCH = BNC / 8;             // 16-B chunks per pixel row
@@ -239,9 +241,126 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
   }
 }
 
+// ---- stem (7x7/2, Cin packed to 4) weight gradient: ALL 7 filter rows in one workgroup ---------------------
+// The generic kernel gives every filter row its own workgroups, so the 411 MB dY (N=64) is re-read 7 times and
+// half of each 128-row cout tile is padding.  Here a workgroup owns the whole [64 cout][7 rows][32] result for a
+// pixel range: dY is staged once per K-step and used against the 7 image rows (wave w: cout half w&1, filter rows
+// {0..3} or {4..6}).  Split-K over pixels into fp32 slabs as above.
+struct StemWgradArgs {
+  const bf16_t* XP;   // [N][H+6][W+6][4]
+  const bf16_t* DY;   // [N][P][Q][*], pixel stride lddy, 64 channels
+  float* OUT;         // slabs [split][64][7][32]
+  int IHp, IWp, P, Q, lddy, M, steps_per_split;
+};
+
+__global__ void __launch_bounds__(256, 2) k_wgrad_stem(StemWgradArgs a) {
+  constexpr int KPS = 32;
+  constexpr int PA = 64 * 2 + 64, PB = 32 * 2;                 // LDS pitches (bytes): 48 / 16 dwords = conflict-free tr reads
+  constexpr int A_BYTES = KPS * PA, B_BYTES = 7 * KPS * PB, STAGE = A_BYTES + B_BYTES;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int chalf = wid & 1, tgrp = wid >> 1;
+  const int t0 = tgrp ? 4 : 0, nt = tgrp ? 3 : 4;
+  const int split = blockIdx.x;
+  const int step0 = split * a.steps_per_split;
+  const int total_steps = (a.M + KPS - 1) / KPS;
+  const int nsteps = min(a.steps_per_split, total_steps - step0);
+  const int PQ = a.P * a.Q;
+
+  // loaders: dY 32 rows x 8 chunks = 256 chunks (1 per thread); image 7 x 32 rows x 4 chunks = 896 (4 passes)
+  const int a_row = tid >> 3, a_cc = tid & 7;
+  const int b_cc = tid & 3, b_row = (tid >> 2) & 31, b_t0 = tid >> 7;          // tap = b_t0 + 2*pass
+  int xn, xp, xq;                                                              // pixel of row b_row
+  {
+    const int m = step0 * KPS + b_row;
+    xn = m / PQ; const int rem = m - xn * PQ; xp = rem / a.Q; xq = rem - xp * a.Q;
+  }
+  int ld_m = step0 * KPS;
+  u32x4 ra, rb[4];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#define YV1_STEM_LOAD()                                                                                          \
+  {                                                                                                              \
+    const int ma = ld_m + a_row;                                                                                 \
+    const bool oka = ma < a.M;                                                                                   \
+    const u32x4 va = *reinterpret_cast<const u32x4*>(a.DY + (oka ? (size_t)ma * a.lddy + a_cc * 8 : (size_t)0)); \
+    ra = oka ? va : zero4;                                                                                       \
+    const bool okb = ld_m + b_row < a.M;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+      const int tap = b_t0 + 2 * i;                                                                              \
+      const bool ok = okb && tap < 7;                                                                            \
+      const size_t off = ok ? ((size_t)(xn * a.IHp + 2 * xp + tap) * a.IWp + 2 * xq) * 4 + b_cc * 8 : (size_t)0; \
+      const u32x4 v = *reinterpret_cast<const u32x4*>(a.XP + off);                                               \
+      rb[i] = ok ? v : zero4;                                                                                    \
+    }                                                                                                            \
+    xq += KPS;                                                                                                   \
+    while (xq >= a.Q) { xq -= a.Q; ++xp; }                                                                       \
+    while (xp >= a.P) { xp -= a.P; ++xn; }                                                                       \
+    ld_m += KPS;                                                                                                 \
+  }
+#define YV1_STEM_STORE(BUF_)                                                                                     \
+  {                                                                                                              \
+    unsigned char* sa_ = smem + (BUF_) * STAGE;                                                                  \
+    unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
+    *reinterpret_cast<u32x4*>(sa_ + a_row * PA + a_cc * 16) = ra;                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+      const int tap = b_t0 + 2 * i;                                                                              \
+      if (tap < 7) *reinterpret_cast<u32x4*>(sb_ + (tap * KPS + b_row) * PB + b_cc * 16) = rb[i];                \
+    }                                                                                                            \
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3, h = g >> 1;
+  const int chan_off = 16 * (g & 1) + 4 * tp;
+  if (nsteps > 0) { YV1_STEM_LOAD(); YV1_STEM_STORE(0); }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) YV1_STEM_LOAD();
+    const unsigned char* sa = smem + cur * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KPS / 16; ++ks) {
+      const int prow = ks * 16 + 8 * h + tq;
+      const int acol = chalf * 32 + chan_off;
+      const bf16x4 alo = lds_read_tr16(sa + prow * PA + acol * 2);
+      const bf16x4 ahi = lds_read_tr16(sa + (prow + 4) * PA + acol * 2);
+      const bf16x8 fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+          const unsigned char* tb = sb + (size_t)(t0 + t) * KPS * PB;
+          const bf16x4 blo = lds_read_tr16(tb + prow * PB + chan_off * 2);
+          const bf16x4 bhi = lds_read_tr16(tb + (prow + 4) * PB + chan_off * 2);
+          const bf16x8 fb = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (st + 1 < nsteps) YV1_STEM_STORE(cur ^ 1);
+    __syncthreads();
+  }
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* out = a.OUT + (size_t)split * 64 * 224;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = chalf * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        out[(size_t)k * 224 + (t0 + t) * 32 + l31] = acc[t][e];
+      }
+    }
+  }
+}
+
+
 template <int BMC, int BNC, int WM, int WN, int KP>
 int launch(WgradArgs& a, int nblocks, hipStream_t stream) {
-  constexpr int STAGE = KP * (BMC * 2 + 64) + KP * (BNC * 2 + 64);
+  constexpr int STAGE = KP * (BMC == 32 ? 64 : BMC * 2 + 64) + KP * (BNC == 32 ? 64 : BNC * 2 + 64);
   if (2 * STAGE > 64 * 1024) {
     static bool once = false;
     if (!once) {
@@ -352,34 +471,42 @@ extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
 
 // Stem weight gradient: x is the packed NHWC4 image [N][H+6][W+6][4]; dw comes out as [Cout][7][32]
 // (element s*4+c of filter row r), the layout yv1_conv2d_stem_fwd_bf16 consumes.
+namespace {
+int stem_plan(int M, int* steps) {
+  const int total_steps = (M + 31) / 32;
+  int splits = 1024;
+  if (splits > total_steps / 8) splits = total_steps / 8 > 0 ? total_steps / 8 : 1;
+  *steps = (total_steps + splits - 1) / splits;
+  return (total_steps + *steps - 1) / *steps;
+}
+}  // namespace
+
 extern "C" size_t yv1_conv2d_stem_wgrad_workspace_bytes(int N, int H, int W, int Cout) {
-  const Plan p = make_plan(N * (H / 2) * (W / 2), 32, Cout, 7);
-  return p.splitK > 1 ? (size_t)p.splitK * Cout * 7 * 32 * sizeof(float) : 0;
+  int steps;
+  const int splits = stem_plan(N * (H / 2) * (W / 2), &steps);
+  return (size_t)splits * Cout * 7 * 32 * sizeof(float);
 }
 
 extern "C" int yv1_conv2d_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int N, int H, int W, int Cout,
                                           int lddy, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (!xp || !dy || !dw || N <= 0 || (H & 1) || (W & 1)) return YV1_ERR_BAD_ARG;
-  WgradArgs a;
-  a.X = (const bf16_t*)xp; a.DY = (const bf16_t*)dy;
-  a.N = N; a.IH = H + 6; a.IW = W + 6; a.ldx = 4;
-  a.P = H / 2; a.Q = W / 2; a.lddy = lddy;
-  a.Cin = 32; a.Cout = Cout; a.R = 7; a.S = 1;
-  a.ah = 2; a.bh = 1; a.ch = 0; a.aw = 2; a.bw = 0; a.cw = 0;
+  if (!xp || !dy || !dw || !workspace || N <= 0 || (H & 1) || (W & 1)) return YV1_ERR_BAD_ARG;
+  if (Cout != 64 || lddy % 8) return YV1_ERR_UNSUPPORTED;
+  StemWgradArgs a;
+  a.XP = (const bf16_t*)xp; a.DY = (const bf16_t*)dy; a.OUT = (float*)workspace;
+  a.IHp = H + 6; a.IWp = W + 6; a.P = H / 2; a.Q = W / 2; a.lddy = lddy;
   a.M = N * a.P * a.Q;
-  const Plan p = make_plan(a.M, 32, Cout, 7);
-  const size_t need = p.splitK > 1 ? (size_t)p.splitK * Cout * 7 * 32 * sizeof(float) : 0;
-  if (need > workspace_bytes || (need && !workspace)) return YV1_ERR_WORKSPACE;
-  a.splitK = p.splitK; a.steps_per_split = p.steps; a.CT = p.CT; a.KT = p.KT;
-  a.OUT = p.splitK > 1 ? (float*)workspace : dw;
-  const int nblocks = p.splitK * p.KT * p.CT * 7;
-  int rc = run_plan(p, a, nblocks, stream);
-  if (rc) return rc;
-  if (p.splitK > 1) {
-    const long long n = (long long)Cout * 7 * 32;
-    const int blocks = (int)((n / 4 + 15) / 16);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, p.splitK);
-    YV1_LAUNCH_CHECK();
+  const int splits = stem_plan(a.M, &a.steps_per_split);
+  if ((size_t)splits * 64 * 224 * sizeof(float) > workspace_bytes) return YV1_ERR_WORKSPACE;
+  constexpr int STAGE = 32 * (64 * 2 + 64) + 7 * 32 * (32 * 2);
+  static bool once = false;
+  if (!once) {
+    YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad_stem, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+    once = true;
   }
+  hipLaunchKernelGGL(k_wgrad_stem, dim3(splits), dim3(256), 2 * STAGE, stream, a);
+  YV1_LAUNCH_CHECK();
+  const long long n = 64ll * 7 * 32;
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((int)((n / 4 + 15) / 16)), dim3(256), 0, stream, (const float*)workspace, dw, n, splits);
+  YV1_LAUNCH_CHECK();
   return YV1_OK;
 }

@@ -91,6 +91,18 @@ class HipBackbone(nn.Module):
         w.refresh()
         return w
 
+    def refresh_all_weights(self):
+        """bf16 shadow copies of every convolution weight, refreshed in one multi-tensor launch."""
+        ws = []
+        for m in self.modules():
+            if isinstance(m, ConvParam):
+                w = self._convw.get(m)
+                if w is None or w.param is not m.weight:
+                    w = ops.ConvWeights(m.weight, m.kernel_size, m.stride, m.padding, stem=(m.in_channels == 3))
+                    self._convw[m] = w
+                ws.append(w)
+        ops.refresh_many(ws)
+
     def forward(self, x):
         if not x.is_cuda:
             raise _lib.Yv1Error("yolo_v1_amd backbones run on the GPU only; there is no CPU fallback")

@@ -90,6 +90,47 @@ class ConvWeights:
         self.version = ver
 
 
+def refresh_many(weights):
+    """Refreshes every stale ConvWeights of ``weights`` with as few launches as possible (one multi-tensor
+    launch per 40 weights instead of one launch per weight)."""
+    import ctypes
+    stale = []
+    for w in weights:
+        p = w.param
+        ver = (p._version, _WEIGHT_EPOCH[0])
+        if w.fwd is not None and ver == w.version and w.fwd.device == p.device:
+            continue
+        if w.stem:
+            w.refresh()
+            continue
+        dev = p.device
+        taps = w.k * w.k
+        if w.fwd is None or w.fwd.device != dev:
+            w.fwd = torch.empty((w.Opad, taps, w.Ipad), dtype=torch.bfloat16, device=dev)
+            w.tr = torch.empty((w.Ipad, taps, w.Opad), dtype=torch.bfloat16, device=dev) if w.need_dgrad else None
+        stale.append((w, ver))
+    if not stale:
+        return
+    L = lib()
+    maxn = L.yv1_prep_weights_max_tensors()
+    dev = stale[0][0].param.device
+    for i in range(0, len(stale), maxn):
+        chunk = stale[i:i + maxn]
+        n = len(chunk)
+        PA, IA, LA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * (4 * n)
+        strides = []
+        for w, _ in chunk:
+            strides.extend(w.param.stride())
+        check(L.yv1_prep_weights_multi(PA(*[w.param.data_ptr() for w, _ in chunk]), LA(*strides),
+                                       IA(*[w.O for w, _ in chunk]), IA(*[w.I for w, _ in chunk]),
+                                       IA(*[w.k for w, _ in chunk]), IA(*[w.Opad for w, _ in chunk]),
+                                       IA(*[w.Ipad for w, _ in chunk]), PA(*[w.fwd.data_ptr() for w, _ in chunk]),
+                                       PA(*[(w.tr.data_ptr() if w.tr is not None else None) for w, _ in chunk]), n,
+                                       stream_ptr(dev)), "yv1_prep_weights_multi")
+    for w, ver in stale:
+        w.version = ver
+
+
 # ------------------------------------------------------------------ convolution
 def conv_out_hw(H, W, k, stride, pad):
     return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
