@@ -254,3 +254,38 @@ def test_graphed_step_is_bitwise_the_eager_step():
     a.eval(); b.eval()
     with torch.no_grad():
         assert torch.equal(a(images), b(images))
+
+
+def test_batched_eval_loop_matches_per_image_oracle_pipeline():
+    """run_test_mAP (batched forward + batched GPU decoder/NMS + host voc_eval) against the reference's
+    per-image pipeline restated with the oracle decoder and oracle voc_eval on the same network outputs."""
+    from collections import defaultdict
+    from oracle import boxes as obx
+    from oracle import voc as ov
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    from yolo_v1_amd.utils.utils import VOC_CLASSES, run_test_mAP
+    from yolo_v1_amd.utils.YOLODataLoader import yoloDataset
+    torch.manual_seed(3)
+    net = resnet50(S=7).to(DEV).eval()
+    ds = yoloDataset(None, train=False, with_file_path=True, S=7, length=10, image_size=128)
+    target = ds.synthetic_ground_truth()
+
+    class Q:
+        def info(self, m):
+            pass
+    got = run_test_mAP(net, {k: [list(b) for b in v] for k, v in target.items()}, ds, len(ds), S=2, device=DEV,
+                       logger=Q(), batch_size=4)
+    # reference pipeline, one image at a time (utils/utils.py:393-411)
+    preds = defaultdict(list)
+    with torch.no_grad():
+        for i in range(len(ds)):
+            img, _, fname = ds[i]
+            pred = net(img[None].to(DEV)).cpu().numpy()
+            bx, cl, pr, _ = obx.decoder(pred, 2, 2, 0.005, 0.45)
+            if len(pr) == 1 and pr[0] == 0:
+                continue
+            bx = np.clip(bx, 0.0, 1.0)
+            for j in range(len(pr)):
+                preds[VOC_CLASSES[int(cl[j])]].append([fname.split('.')[0], float(pr[j])] + [int(v * 128) for v in bx[j]])
+    want, _ = ov.voc_eval(preds, target, VOC_CLASSES)
+    assert abs(got - want) < 1e-12, (got, want)

@@ -48,7 +48,7 @@ class yoloDataset(data.Dataset):
 
     def __init__(self, list_file=None, train=True, transform=None, device='cpu', little_train=False,
                  with_file_path=False, S=7, B=2, C=20, test_mode=False, synthetic=None, length=512, objs=3,
-                 seed=1234, image_loader=None):
+                 seed=1234, image_loader=None, image_size=None):
         self.train = train
         self.transform = transform
         self.S, self.B, self.C = S, B, C
@@ -59,6 +59,8 @@ class yoloDataset(data.Dataset):
         self.objs = objs
         self.seed = seed
         self.image_loader = image_loader
+        if image_size is not None:
+            self.image_size = image_size
         self.fnames = []
         if not self.synthetic:
             with open(list_file) as f:
@@ -93,6 +95,20 @@ class yoloDataset(data.Dataset):
         wh = torch.rand(self.objs, 2, generator=g) * 0.85 + 0.05
         labels = torch.randint(0, self.C, (self.objs,), generator=g)
         return img, torch.cat([cxcy, wh], 1), labels, "synthetic_%06d.jpg" % idx
+
+    def synthetic_ground_truth(self, n=None):
+        """voc_eval target dict {(image_id, class_name): [[x0,y0,x1,y1], ...]} of the synthetic samples, built the
+        way the reference builds it from label files (utils/utils.py:326-345,:356-387)."""
+        from collections import defaultdict
+        from .utils import VOC_CLASSES
+        target = defaultdict(list)
+        sz = self.image_size
+        for idx in range(self.num_samples if n is None else n):
+            _, boxes, labels, fname = self._synthetic_item(idx)
+            for (x, y, w, h), lab in zip(boxes.tolist(), labels.tolist()):
+                target[(fname.split('.')[0], VOC_CLASSES[lab])].append(
+                    [int((x - 0.5 * w) * sz), int((y - 0.5 * h) * sz), int((x + 0.5 * w) * sz), int((y + 0.5 * h) * sz)])
+        return target
 
     def __getitem__(self, idx):
         if self.synthetic:

@@ -173,6 +173,77 @@ def voc_eval(preds, target, VOC_CLASSES=VOC_CLASSES, threshold=0.5, use_07_metri
     return mAP
 
 
+def from_img_path_get_label_list(img_path, img_size=(448, 448)):
+    """darknet label file next to the image -> [[label, x0, y0, x1, y1], ...] in pixels; utils/utils.py:326-345."""
+    label_path = img_path.replace('JPEGImages', 'labels').replace('jpg', 'txt')
+    out = []
+    with open(label_path, 'r') as f:
+        for line in f:
+            ll = line.strip().split(' ')
+            x, y, w, h = float(ll[1]), float(ll[2]), float(ll[3]), float(ll[4])
+            out.append([int(ll[0]), int((x - 0.5 * w) * img_size[0]), int((y - 0.5 * h) * img_size[1]),
+                        int((x + 0.5 * w) * img_size[0]), int((y + 0.5 * h) * img_size[1])])
+    return out
+
+
+def prep_test_data(file_path, little_test=None):
+    """ground-truth dict {(image_id, class_name): [[x0,y0,x1,y1], ...]} for voc_eval; utils/utils.py:356-387."""
+    from collections import defaultdict
+    target = defaultdict(list)
+    with open(file_path) as f:
+        files = [ln.strip() for ln in f.readlines()]
+    if little_test:
+        files = files[:little_test]
+    for image_file in files:
+        image_id = image_file.split('/')[-1].split('.')[0]
+        for lab in from_img_path_get_label_list(image_file):
+            target[(image_id, VOC_CLASSES[lab[0]])].append(lab[1:])
+    return target
+
+
+def detections_from_batch(pred, fnames, preds, S=7, B=2, thresh=0.005, nms_th=.45, img_size=(448, 448)):
+    """Decodes a whole batch on the GPU and appends the reference's detection records
+    ``[img_id, conf, int(x1*w), int(y1*h), int(x2*w), int(y2*h)]`` (utils/utils.py:405-411) to
+    ``preds[class_name]``: boxes clamped to [0,1] first, the all-zero placeholder box skipped."""
+    boxes, cls, probs, _, counts, ncand = decode_batch(pred, S, B, thresh, nms_th)
+    boxes = boxes.clamp(min=0., max=1.).cpu()          # one D2H copy per tensor per batch
+    cls, probs, counts, ncand = cls.cpu(), probs.cpu(), counts.cpu(), ncand.cpu()
+    w, h = img_size
+    for n, fname in enumerate(fnames):
+        if int(ncand[n]) == 0:                         # `len(confs) == 1 and confs[0] == 0` -> continue (:408)
+            continue
+        img_id = fname.split('/')[-1].split('.')[0]
+        for j in range(int(counts[n])):
+            b = boxes[n, j]
+            preds[VOC_CLASSES[int(cls[n, j])]].append([img_id, float(probs[n, j]), int(b[0] * w), int(b[1] * h),
+                                                       int(b[2] * w), int(b[3] * h)])
+    return preds
+
+
+def run_test_mAP(YOLONet, target, test_datasets, data_len, S=7, device='cuda:0', reversed=False, logger=None,
+                 little_test=None, batch_size=64):
+    """mAP over a dataset yielding (image, target, fname); utils/utils.py:389-418.
+
+    The reference forwards one image at a time and decodes it in Python; here ``batch_size`` images go
+    through the backbone together and one workgroup per image decodes + suppresses them on the GPU.
+    Results are identical per image (eval-mode BatchNorm is batch-independent).  ``reversed`` (a layout
+    swap for a third-party loss, testCodes/tensor_test.py:99-107) is not supported."""
+    from collections import defaultdict
+    if reversed:
+        raise _lib.Yv1Error("run_test_mAP(reversed=True) is not supported")
+    preds = defaultdict(list)
+    n_total = len(test_datasets) if little_test is None else min(little_test, len(test_datasets))
+    with torch.no_grad():
+        for i0 in range(0, n_total, batch_size):
+            items = [test_datasets[i] for i in range(i0, min(n_total, i0 + batch_size))]
+            images = torch.stack([it[0] for it in items]).to(device)
+            fnames = [it[2] for it in items]
+            pred = YOLONet(images)
+            detections_from_batch(pred, fnames, preds, S=S, img_size=(images.shape[3], images.shape[2]))
+    (logger.info if logger else print)('---start evaluate---')
+    return voc_eval(preds, target, VOC_CLASSES=VOC_CLASSES, threshold=0.5, use_07_metric=False, logger=logger)
+
+
 def bbox_un_norm(bboxes, img_size=(448, 448)):
     """utils/utils.py:347-354 (in place, truncating like ``int()``)."""
     (w, h) = img_size
