@@ -61,9 +61,18 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
 
-  // block -> (split, cout tile, cin tile, tap): taps innermost so the blocks that re-read the same
-  // dY / X pixel range are launched together
+  // block -> (split, cout tile, cin tile, tap), taps innermost, through an XCD-aware (bijective) remap: the
+  // workgroups that share an XCD (blockIdx % 8) get CONSECUTIVE logical ids, so the taps / channel tiles that
+  // re-read one dY / X pixel range run next to each other on one L2 instead of being dealt over all eight
+  // (PMC: 2.2x the algorithmic operand bytes were fetched without it)
+  // Measured per layer: a clear win on the large feature maps (56x56, 112x112: up to 1.6x), a small loss on
+  // the 28x28-and-below layers whose operands sit in the Infinity Cache anyway -> only used for M >= 100k pixels.
   int b = blockIdx.x;
+  if (a.M >= 100000) {
+    const int nwg = gridDim.x, o = blockIdx.x;
+    const int xcd = o & 7, q = nwg >> 3, r8 = nwg & 7;
+    b = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (o >> 3);
+  }
   const int taps = a.R * a.S;
   const int tap = b % taps; b /= taps;
   const int ct = b % a.CT; b /= a.CT;
