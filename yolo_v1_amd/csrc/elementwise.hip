@@ -55,12 +55,28 @@ __global__ void k_reduce_rows(const float* __restrict__ in, float* __restrict__ 
   out[(size_t)blockIdx.y * W + c] = (s0 + s1) + (s2 + s3);
 }
 
-// partial (sum, sumsq) rows [rows][2][Cseg] -> one row inside a wider [2][ldo] table at channel c0
-__global__ void k_stats_merge(const float* __restrict__ in, int rows, int Cseg, float* __restrict__ out, int ldo, int c0) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * Cseg) return;
+// partial (sum, sumsq) rows [rows][2][Cseg] -> one row inside a wider [2][ldo] table at channel c0.
+// 1024 threads = 64 columns x 16 row lanes (rows can be thousands: one serial chain per column took 100 us).
+__global__ void __launch_bounds__(1024) k_stats_merge(const float* __restrict__ in, int rows, int Cseg, float* __restrict__ out,
+                                                      int ldo, int c0) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < 2 * Cseg) {
+    int r = ty;
+    for (; r + 16 < rows; r += 32) {
+      s0 += in[(size_t)r * 2 * Cseg + i];
+      s1 += in[(size_t)(r + 16) * 2 * Cseg + i];
+    }
+    for (; r < rows; r += 16) s0 += in[(size_t)r * 2 * Cseg + i];
+  }
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty != 0 || i >= 2 * Cseg) return;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += in[(size_t)r * 2 * Cseg + i];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][tx];
   const int half = i / Cseg, c = i - half * Cseg;
   out[(size_t)half * ldo + c0 + c] = s;
 }
@@ -685,7 +701,7 @@ extern "C" int yv1_reduce_rows(const float* in, float* out, int rows, int W, int
 // (DenseNet: one statistics table per dense block, filled as each 32-channel slice is produced).
 extern "C" int yv1_stats_merge(const float* partials, int rows, int Cseg, float* table, int ldo, int c0, hipStream_t stream) {
   if (!partials || !table || rows <= 0 || Cseg <= 0 || c0 < 0 || c0 + Cseg > ldo) return YV1_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_stats_merge, dim3((2 * Cseg + 63) / 64), dim3(64), 0, stream, partials, rows, Cseg, table, ldo, c0);
+  hipLaunchKernelGGL(k_stats_merge, dim3((2 * Cseg + 63) / 64), dim3(1024), 0, stream, partials, rows, Cseg, table, ldo, c0);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
