@@ -42,7 +42,9 @@ class BackboneFn(torch.autograd.Function):
     def forward(ctx, net, images, *params):
         _lib.require_cuda(images)
         train = net.training
-        need_bwd = any(ctx.needs_input_grad)
+        # activations are only kept for a training-mode forward: eval-mode BatchNorm (running statistics) has no
+        # backward here, a later .backward() then fails loudly instead of differentiating the wrong function
+        need_bwd = any(ctx.needs_input_grad) and train
         with torch.no_grad():
             pred, saved = net._run_forward(images, train, need_bwd)
         ctx.net = net
@@ -55,7 +57,8 @@ class BackboneFn(torch.autograd.Function):
         net, saved = ctx.net, ctx.saved
         ctx.saved = None
         if saved is None:
-            raise _lib.Yv1Error("backward called twice or forward ran without saving (no_grad)")
+            raise _lib.Yv1Error("backward through the HIP backbone needs a training-mode forward with gradients "
+                                "enabled (and can run only once per forward)")
         with torch.no_grad():
             grads = net._run_backward(saved, gpred)
         out = []
