@@ -385,7 +385,16 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     if (dbg < 0) { const char* e = getenv("YV1_CONV_DBG"); dbg = e ? atoi(e) : 0; }
     a.dbg = dbg;
   }
-  const bool k64 = (a.Cin % 64) == 0;
+  // BK: 64 halves the barriers per MAC but its 64 KB of LDS allows only 2 workgroups per CU; BK 32 (32 KB, 4 per
+  // CU) overlaps the load and MFMA phases of more workgroups.  Measured per layer: BK 32 wins on the large,
+  // bandwidth-bound feature maps (56x56 and up), BK 64 on the deep compute-bound layers.
+  bool k64 = (a.Cin % 64) == 0 && a.M < 150000;
+  {
+    static int forced = -1;                  // tuning: YV1_CONV_BK=32|64 overrides the choice
+    if (forced < 0) { const char* e = getenv("YV1_CONV_BK"); forced = e ? atoi(e) : 0; }
+    if (forced == 32) k64 = false;
+    if (forced == 64) k64 = (a.Cin % 64) == 0;
+  }
   int bn = 0;
   const int bm = choose_cfg(a.M, a.Cout, a.Cin, &bn);
   if (bm == 256 && bn == 128 && k64) return launch<256, 128, 64, 4, 2>(a, stream);
