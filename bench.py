@@ -26,6 +26,19 @@ TRAIN_GFLOP_PER_IMG = {("resnet", 7): 103.25, ("resnet", 14): 97.22, ("densenet"
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_traffic(backbone, S, batch):
+    """HBM bytes per step from the PMC passes committed under profiles/ (tools/pmc_traffic.py); None when the
+    committed measurement is for a different workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if t.get("workload") != "%s S=%d batch %d" % (backbone, S, batch):
+        return None
+    return t.get("hbm_bytes_per_step")
+
+
 def cpu_baseline(steps=60, warmup=3):
     """BASELINE.json configs[0]: ResNet-50 448x448 S=7 batch 2 fp32 on the host cores, through the CPU
     oracle (our restatement of the reference modules; the reference itself never travels)."""
@@ -143,7 +156,8 @@ def main():
                        "optimizer": "fused HIP SGD" if args.fused_sgd else "torch.optim.SGD",
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager launches"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": measured_traffic(args.backbone, args.S, args.batch),
                          "note": "whole training step of one GPU: %.2f algorithmic conv GFLOP/img x %d img / %.3f ms "
                                  "(HIP-event time of the step on the launch stream)" % (gflop, args.batch, step_s_dev * 1e3)},
             "final_loss": round(final_loss, 5),
