@@ -171,9 +171,11 @@ class DenseNet(HipBackbone):
         dev = pred.device
         N = yh.N
         wh = self.cw(self.layer6)
+        # weight gradients run on a side stream (see OriginResNet._run_backward)
+        side = ops.SideStream(dev, enabled=self._grad_ready_hook is None and self.wgrad_side_stream)
         dyh = ops.new_act(N, yh.H, yh.W, wh.Opad, dev)
         grads[self.bn_end.weight], grads[self.bn_end.bias] = ops.head_bwd(gpred, pred, yh, sh, self.bn_end, dyh)
-        grads[self.layer6.weight] = ops.conv_wgrad(t5, dyh, wh)
+        grads[self.layer6.weight] = ops.conv_wgrad(t5, dyh, wh, side)
         dt5 = ops.new_act(N, t5.H, t5.W, t5.C, dev)
         ops.conv_dgrad(dyh, wh, dt5)
         G = ops.new_act(N, buf.H, buf.W, buf.C, dev)         # gradient of the last block's feature buffer
@@ -186,12 +188,12 @@ class DenseNet(HipBackbone):
                 for (layer, cin, st1, t1, y1, st2, t2) in reversed(lrecs):
                     w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
                     dy2 = G.window(cin, self.growth)          # the slice is complete: every later layer has added to it
-                    grads[layer.conv2.weight] = ops.conv_wgrad(t2, dy2, w2)
+                    grads[layer.conv2.weight] = ops.conv_wgrad(t2, dy2, w2, side)
                     dt2 = ops.new_act(N, t2.H, t2.W, t2.C, dev)
                     ops.conv_dgrad(dy2, w2, dt2)
                     dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
                     grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward(dt2, y1, st2, layer.norm2, dy1, 2)
-                    grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1)
+                    grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1, side)
                     dt1 = ops.new_act(N, t1.H, t1.W, cin, dev)
                     ops.conv_dgrad(dy1, w1, dt1)
                     grads[layer.norm1.weight], grads[layer.norm1.bias] = ops.bn_backward(
@@ -203,7 +205,7 @@ class DenseNet(HipBackbone):
                 wc = self.cw(tr.conv)
                 dyc = ops.new_act(N, yc.H, yc.W, yc.C, dev)
                 ops.avgpool_bwd(g_first, dyc)
-                grads[tr.conv.weight] = ops.conv_wgrad(t, dyc, wc)
+                grads[tr.conv.weight] = ops.conv_wgrad(t, dyc, wc, side)
                 dt = ops.new_act(N, t.H, t.W, t.C, dev)
                 ops.conv_dgrad(dyc, wc, dt)
                 G = ops.new_act(N, buf.H, buf.W, buf.C, dev)
@@ -216,7 +218,8 @@ class DenseNet(HipBackbone):
         ops.maxpool_bwd(z0, g_first, dz0, pidx)
         dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
         grads[F.norm0.weight], grads[F.norm0.bias] = ops.bn_backward(dz0, y0, s0, F.norm0, dy0, 2)
-        grads[F.conv0.weight] = ops.stem_wgrad(xp, dy0, w0, H, W)
+        grads[F.conv0.weight] = ops.stem_wgrad(xp, dy0, w0, H, W, side)
+        side.join()
         self._emit(grads, [F.norm0.weight, F.norm0.bias, F.conv0.weight])
         return grads
 

@@ -147,11 +147,14 @@ class ResNet(HipBackbone):
         x, yh, sh, pred = rec["head"]
         dev = pred.device
         N = yh.N
+        # weight gradients overlap with the dgrad / BN chain on a side stream, unless a gradient-ready hook
+        # (overlapped RCCL all-reduce issued from the main stream) needs them in main-stream order
+        side = ops.SideStream(dev, enabled=self._grad_ready_hook is None and self.wgrad_side_stream)
         wh = self.cw(self.layer6)
         dyh = ops.new_act(N, yh.H, yh.W, wh.Opad, dev)
         dg, db = ops.head_bwd(gpred, pred, yh, sh, self.bn_end, dyh)
         grads[self.bn_end.weight], grads[self.bn_end.bias] = dg, db
-        grads[self.layer6.weight] = ops.conv_wgrad(x, dyh, wh)
+        grads[self.layer6.weight] = ops.conv_wgrad(x, dyh, wh, side)
         g = ops.new_act(N, x.H, x.W, x.C, dev)
         ops.conv_dgrad(dyh, wh, g)
         self._emit(grads, [self.bn_end.weight, self.bn_end.bias, self.layer6.weight])
@@ -166,21 +169,21 @@ class ResNet(HipBackbone):
                 grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
                 dyd = ops.new_act(N, yd.H, yd.W, yd.C, dev)
                 grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
-                grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd)
+                grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side)
             else:
                 # identity shortcut: the masked gradient is also the shortcut's contribution to g_in
                 grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask, dres=g_in)
-            grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3)
+            grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side)
             dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
             ops.conv_dgrad(dy3, w3, dz2)
             dy2 = ops.new_act(N, y2.H, y2.W, y2.C, dev)
             grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
-            grads[blk.conv2.weight] = ops.conv_wgrad(z1, dy2, w2)
+            grads[blk.conv2.weight] = ops.conv_wgrad(z1, dy2, w2, side)
             dz1 = ops.new_act(N, z1.H, z1.W, z1.C, dev)
             ops.conv_dgrad(dy2, w2, dz1)
             dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
             grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
-            grads[blk.conv1.weight] = ops.conv_wgrad(x, dy1, w1)
+            grads[blk.conv1.weight] = ops.conv_wgrad(x, dy1, w1, side)
             if yd is not None:
                 ops.conv_dgrad(dy1, w1, g_in, accumulate=False)
                 ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate
@@ -195,7 +198,8 @@ class ResNet(HipBackbone):
         ops.maxpool_bwd(z0, g, dz0, pidx)
         dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
         grads[self.bn1.weight], grads[self.bn1.bias] = ops.bn_backward(dz0, y0, s0, self.bn1, dy0, 2)
-        grads[self.conv1.weight] = ops.stem_wgrad(xp, dy0, w0, H, W)
+        grads[self.conv1.weight] = ops.stem_wgrad(xp, dy0, w0, H, W, side)
+        side.join()
         self._emit(grads, [self.bn1.weight, self.bn1.bias, self.conv1.weight])
         return grads
 

@@ -7,6 +7,8 @@ backward needs; its backward walks the layers in reverse with explicit dgrad / w
 launches and hands every parameter gradient back to autograd in one go, so ``loss.backward()``
 and any ``torch.optim`` optimizer keep working unchanged (train.py:170-172).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -75,6 +77,7 @@ class HipBackbone(nn.Module):
         super().__init__()
         self._convw = {}      # ConvParam -> ops.ConvWeights
         self._grad_ready_hook = None
+        self.wgrad_side_stream = os.environ.get("YV1_WGRAD_SIDE_STREAM", "1") != "0"
 
     def set_grad_ready_hook(self, fn):
         """``fn([(param, grad), ...])`` is called from inside the backward executor as soon as the

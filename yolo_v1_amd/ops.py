@@ -177,30 +177,80 @@ def conv_dgrad(dy, w, dx, accumulate=False):
           "yv1_conv2d_dgrad_nhwc_bf16")
 
 
-def conv_wgrad(x, dy, w):
-    """Returns the fp32 gradient as an OIHW view whose storage is [O][kh][kw][I] (channels_last)."""
+class SideStream:
+    """Runs leaf work (weight gradients: nothing else in the backward consumes them) on a second HIP stream so it
+    overlaps with the dgrad / BatchNorm chain on the main stream -- eagerly and inside a captured hipGraph
+    (fork/join).  Buffers are allocated on the main stream and kept alive until ``join()``, so the caching
+    allocator can never hand memory the side stream still reads to later main-stream work."""
+
+    def __init__(self, device, enabled=True):
+        self.main = torch.cuda.current_stream(device)
+        self.side = _side_stream_for(device) if enabled else None
+        self.keep = []
+
+    def run(self, fn, *keep_alive):
+        """fn() launches kernels; they are ordered after everything issued on the main stream so far."""
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        self.keep.extend(keep_alive)
+        return out
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+        self.keep = []
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream_for(device):
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[key]
+
+
+def conv_wgrad(x, dy, w, side=None):
+    """Returns the fp32 gradient as an OIHW view whose storage is [O][kh][kw][I] (channels_last).
+    With ``side`` (a SideStream) the kernels run on the side stream."""
     dev = x.t.device
     L = lib()
     taps = w.k * w.k
     g = torch.empty((w.Opad, taps, w.Ipad), dtype=torch.float32, device=dev)
     wsb = L.yv1_conv2d_wgrad_workspace_bytes(x.N, dy.H, dy.W, w.Ipad, w.Opad, w.k)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-    check(L.yv1_conv2d_wgrad_nhwc_bf16(x.p, dy.p, ptr(g), x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, dy.ld, w.k, w.stride, w.pad,
-                                       ptr(ws), wsb, stream_ptr(dev)), "yv1_conv2d_wgrad_nhwc_bf16")
+
+    def launch():
+        check(L.yv1_conv2d_wgrad_nhwc_bf16(x.p, dy.p, ptr(g), x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, dy.ld, w.k, w.stride,
+                                           w.pad, ptr(ws), wsb, stream_ptr(dev)), "yv1_conv2d_wgrad_nhwc_bf16")
+    if side is None:
+        launch()
+    else:
+        side.run(launch, x.t, dy.t, ws, g)
     return g[:w.O].view(w.O, w.k, w.k, w.Ipad).permute(0, 3, 1, 2)
 
 
-def stem_wgrad(xp, dy, w, H, W):
+def stem_wgrad(xp, dy, w, H, W, side=None):
     dev = xp.device
     L = lib()
     g = torch.empty((w.O, 7, 32), dtype=torch.float32, device=dev)
     wsb = L.yv1_conv2d_stem_wgrad_workspace_bytes(dy.N, H, W, w.O)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-    check(L.yv1_conv2d_stem_wgrad_bf16(ptr(xp), dy.p, ptr(g), dy.N, H, W, w.O, dy.ld, ptr(ws), wsb, stream_ptr(dev)),
-          "yv1_conv2d_stem_wgrad_bf16")
     out = torch.empty((w.O, 7, 7, 3), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
     so, si, sh, sw = out.stride()
-    check(L.yv1_unpack_stem_grad(ptr(g), ptr(out), so, si, sh, sw, w.O, stream_ptr(dev)), "yv1_unpack_stem_grad")
+
+    def launch():
+        check(L.yv1_conv2d_stem_wgrad_bf16(ptr(xp), dy.p, ptr(g), dy.N, H, W, w.O, dy.ld, ptr(ws), wsb, stream_ptr(dev)),
+              "yv1_conv2d_stem_wgrad_bf16")
+        check(L.yv1_unpack_stem_grad(ptr(g), ptr(out), so, si, sh, sw, w.O, stream_ptr(dev)), "yv1_unpack_stem_grad")
+    if side is None:
+        launch()
+    else:
+        side.run(launch, xp, dy.t, ws, g, out)
     return out
 
 
