@@ -48,6 +48,14 @@ int yv1_scale_by_device_scalar(float* x, const float* scalar, long long n, yv1_s
 int yv1_decode_nms_batched(const float* pred, int N, int S, int B, int C, double thresh, float nms_th, float* out_boxes,
                            long long* out_cls, float* out_scores, long long* out_keep_idx, int* out_counts,
                            int* out_ncand, yv1_stream_t stream);
+/* ---- target encoder: utils/YOLODataLoader.py:200-230 for a whole batch -------------------------------- */
+/* boxes [N][Kmax][4] fp32 normalised (cx,cy,w,h), labels [N][Kmax] int64, counts [N] (boxes used per image).
+ * target [N][S][S][B*5+C] fp32 is written completely (zeros where no box lands).  Later boxes replace earlier
+ * ones in the same cell; a coordinate of exactly 0 wraps to the last cell (Python's index -1).  *err_flag is
+ * set to 1 when a box falls outside the grid or a label outside [0,C) (the reference raises IndexError). */
+int yv1_encode_targets(const float* boxes, const long long* labels, const int* counts, int N, int Kmax, int S, int B,
+                       int C, float* target, int* err_flag, yv1_stream_t stream);
+
 /* greedy class-agnostic NMS, n <= 896; out_keep: indices into the input in keep order */
 int yv1_nms(const float* boxes, const float* scores, int n, float threshold, long long* out_keep, int* out_count,
             yv1_stream_t stream);

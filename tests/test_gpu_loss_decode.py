@@ -202,3 +202,65 @@ def test_decoder_gt_mode_roundtrip_encode_decode(dev):
     want = np.concatenate([boxes[:, :2] - boxes[:, 2:] / 2, boxes[:, :2] + boxes[:, 2:] / 2], 1)
     for w in want:
         assert np.min(np.abs(got - w).max(1)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_device_encoder_matches_reference_fixture_and_host_encoder():
+    """N3: utils/YOLODataLoader.py:200-230 as one kernel per batch; bit-exact vs the reference-generated fixture
+    and vs the oracle on batches with cell collisions (last writer wins), empty images and the index -1 wrap."""
+    from oracle import boxes as oboxes
+    from yolo_v1_amd.utils.YOLODataLoader import collate_raw, encode_targets_device
+    dev = torch.device("cuda:0")
+    for c in load_cases("encoder_cases.npz"):
+        S = int(c["S"])
+        b = torch.tensor(c["boxes"]).reshape(1, -1, 4).float().to(dev)
+        l = torch.tensor(c["labels"]).reshape(1, -1).long().to(dev)
+        cnt = torch.tensor([b.shape[1]], dtype=torch.int32, device=dev)
+        got = encode_targets_device(b, l, cnt, S)
+        np.testing.assert_array_equal(got[0].cpu().numpy(), c["target"])
+    g = torch.Generator().manual_seed(11)
+    for S in (7, 14):
+        samples = []
+        for i in range(9):
+            k = [0, 1, 2, 5, 12, 40, 3, 3, 7][i]
+            boxes = torch.rand(k, 4, generator=g).clamp_(1e-4, 1.0)
+            if i == 5:
+                boxes[:, :2] = boxes[:, :2] * 0.3                 # 40 boxes crowded into a corner: many collisions
+            if i == 6:
+                boxes[0, 0], boxes[1, 1] = 0.0, 0.0                # ceil(0)-1 = -1: wraps to the last column / row
+            if i == 7:
+                boxes[:, :2] = torch.tensor([[1 / S, 2 / S], [1.0, 1.0], [3 / S, 1 / S]])   # exactly on cell borders
+            samples.append((torch.zeros(1), boxes, torch.randint(0, 20, (k,), generator=g)))
+        _, boxes, labels, counts = collate_raw(samples)
+        got = encode_targets_device(boxes.to(dev), labels.to(dev), counts.to(dev), S).cpu().numpy()
+        for i, smp in enumerate(samples):
+            want = oboxes.encode_target(smp[1].numpy(), smp[2].numpy(), S)
+            np.testing.assert_array_equal(got[i], want, err_msg="S=%d image %d" % (S, i))
+    bad = torch.tensor([[[1.5, 0.5, 0.1, 0.1]]], device=dev)
+    with pytest.raises(IndexError):
+        encode_targets_device(bad, torch.zeros(1, 1, dtype=torch.long, device=dev),
+                              torch.ones(1, dtype=torch.int32, device=dev), 7)
+    with pytest.raises(Exception):
+        encode_targets_device(bad.cpu(), torch.zeros(1, 1, dtype=torch.long), torch.ones(1, dtype=torch.int32), 7)
+
+
+@pytest.mark.gpu
+def test_device_prefetcher_feeds_encoded_batches():
+    from yolo_v1_amd.utils.YOLODataLoader import DevicePrefetcher, collate_raw, yoloDataset
+    dev = torch.device("cuda:0")
+    ds_raw = yoloDataset(None, S=7, length=10, objs=4, raw_targets=True, image_size=64)
+    ds_enc = yoloDataset(None, S=7, length=10, objs=4, image_size=64)
+    loader = torch.utils.data.DataLoader(ds_raw, batch_size=4, shuffle=False, collate_fn=collate_raw, num_workers=0)
+    seen = 0
+    for images, target in DevicePrefetcher(loader, dev, S=7):
+        n = images.shape[0]
+        assert images.is_cuda and tuple(target.shape) == (n, 7, 7, 30)
+        for i in range(n):
+            img, tgt = ds_enc[seen + i]
+            assert torch.equal(images[i].cpu(), img) and torch.equal(target[i].cpu(), tgt)
+        seen += n
+    assert seen == 10
+    # already-encoded host batches pass through the same staging
+    loader2 = torch.utils.data.DataLoader(ds_enc, batch_size=5, shuffle=False, num_workers=0)
+    got = [t.cpu() for _, t in DevicePrefetcher(loader2, dev, S=7)]
+    assert torch.equal(torch.cat(got), torch.stack([ds_enc[i][1] for i in range(10)]))

@@ -97,3 +97,53 @@ def test_gradsync_gloo_world2_averages_into_param_grad():
         want = (a + b) / 2
         torch.testing.assert_close(o0, want)
         torch.testing.assert_close(o1, want)
+
+
+def test_checkpoint_roundtrip_and_pretrained_by_name(tmp_path):
+    """N4: reference-compatible files (train.py:59-78 by-name ImageNet init, :207-209 'module.' prefix, eval.py:63-68)."""
+    import torch
+    from yolo_v1_amd import checkpoint
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    torch.manual_seed(3)
+    net = resnet50(S=14)
+    ref = {k: v.clone() for k, v in net.state_dict().items()}
+    # a torchvision-shaped ImageNet file: backbone keys + the classifier the YOLO net does not have
+    g = torch.Generator().manual_seed(5)
+    pre = {k: torch.randn(v.shape, generator=g) for k, v in ref.items()
+           if k.startswith(('conv1', 'bn1', 'layer1', 'layer2')) and v.dtype.is_floating_point}
+    pre['fc.weight'] = torch.randn(1000, 2048, generator=g)
+    pre['fc.bias'] = torch.randn(1000, generator=g)
+    taken = checkpoint.init_from_pretrained(net, pre)
+    assert set(taken) == set(pre) - {'fc.weight', 'fc.bias'}
+    sd = net.state_dict()
+    for k in ref:
+        assert torch.equal(sd[k], pre[k] if k in taken else ref[k]), k
+    bad = dict(pre)
+    bad['conv1.weight'] = torch.zeros(64, 3, 3, 3)
+    with pytest.raises(ValueError):
+        checkpoint.init_from_pretrained(net, bad)
+
+    path = str(tmp_path / "resnet_sgd_S14_yolo.pth")
+    checkpoint.save(net, path)
+    on_disk = torch.load(path, weights_only=True)
+    assert all(k.startswith('module.') for k in on_disk) and len(on_disk) == len(sd)
+    assert on_disk['module.layer1.0.conv2.weight'].shape == (64, 64, 3, 3) and on_disk['module.conv1.weight'].is_contiguous()
+    net2 = resnet50(S=14)
+    checkpoint.load(net2, path)
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    plain = str(tmp_path / "plain.pth")
+    checkpoint.save(net, plain, data_parallel_prefix=False)
+    net3 = resnet50(S=14)
+    checkpoint.load(net3, plain)
+    assert torch.equal(net3.state_dict()['layer6.weight'], sd['layer6.weight'])
+
+
+def test_collate_raw_pads_boxes_to_batch_max():
+    from yolo_v1_amd.utils.YOLODataLoader import collate_raw, yoloDataset
+    ds = yoloDataset(None, S=7, length=4, objs=3, raw_targets=True, image_size=32)
+    samples = [ds[0], ds[1], (ds[2][0], torch.zeros(0, 4), torch.zeros(0, dtype=torch.long))]
+    imgs, boxes, labels, counts = collate_raw(samples)
+    assert tuple(imgs.shape) == (3, 3, 32, 32) and tuple(boxes.shape) == (3, 3, 4) and tuple(labels.shape) == (3, 3)
+    assert counts.tolist() == [3, 3, 0] and counts.dtype == torch.int32 and labels.dtype == torch.int64
+    assert torch.equal(boxes[1], ds[1][1]) and float(boxes[2].abs().sum()) == 0.0

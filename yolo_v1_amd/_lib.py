@@ -28,6 +28,7 @@ SIGNATURES = {
                                c_p, c_p, c_p, c_p, c_sz, c_p]),
     "yv1_scale_by_device_scalar": (c_i, [c_p, c_p, c_ll, c_p]),
     "yv1_decode_nms_batched": (c_i, [c_p, c_i, c_i, c_i, c_i, c_d, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yv1_encode_targets": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "yv1_nms": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p, c_p]),
     "yv1_iou_matrix": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
     "yv1_convert_cxcywh_to_xyxy": (c_i, [c_p, c_i, c_i, c_p, c_p]),

@@ -19,6 +19,7 @@ ARCH = "gfx950"
 SOURCES = {
     "loss.hip": ["-ffp-contract=off"],
     "decode_nms.hip": ["-ffp-contract=off"],
+    "encode.hip": ["-ffp-contract=off"],
     "conv.hip": [],
     "wgrad.hip": [],
     "elementwise.hip": [],

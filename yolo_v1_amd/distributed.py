@@ -68,14 +68,24 @@ class GradSync:
         if self.pending_bytes >= self.bucket_bytes:
             self._flush()
 
+    def reduce_all(self, pairs):
+        """Everything in ONE collective (nothing left to overlap with: used after a hipGraph replay of
+        forward+backward, where one large message runs the xGMI links at their best rate)."""
+        self.pending.extend(pairs)
+        self._flush()
+        self.finish()
+
     def _flush(self):
         if not self.pending:
             return
         flat = torch.cat([_flat_memory_view(g) for _, g in self.pending])
-        work = None
+        work, averaged = None, False
         if dist.is_initialized():
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.inflight.append((work, flat, [p for p, _ in self.pending],
+            # RCCL averages in the collective itself (no extra pass over the bucket); gloo only sums
+            averaged = flat.is_cuda and dist.get_backend(self.group) == "nccl"
+            op = dist.ReduceOp.AVG if averaged else dist.ReduceOp.SUM
+            work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        self.inflight.append((work, averaged, flat, [p for p, _ in self.pending],
                               [(g.numel(), tuple(g.shape), tuple(g.stride())) for _, g in self.pending]))
         self.pending, self.pending_bytes = [], 0
         self.buckets_issued += 1
@@ -84,10 +94,10 @@ class GradSync:
         """Wait for every bucket, average, write the result into ``param.grad``.  Call once per step,
         after ``loss.backward()`` and before ``optimizer.step()``."""
         self._flush()
-        for work, flat, params, metas in self.inflight:
+        for work, averaged, flat, params, metas in self.inflight:
             if work is not None:
                 work.wait()
-            if self.world > 1:
+            if self.world > 1 and not averaged:
                 flat.mul_(1.0 / self.world)
             chunks = flat.split([m[0] for m in metas])
             # each chunk holds the gradient in the memory order it was produced in; view it with that

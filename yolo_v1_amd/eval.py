@@ -15,9 +15,8 @@ from .utils.YOLODataLoader import yoloDataset
 
 
 def load_checkpoint(net, path, device):
-    sd = torch.load(path, map_location=device, weights_only=True)
-    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
-    return net.load_state_dict(sd)
+    from . import checkpoint
+    return checkpoint.load(net, path, device)
 
 
 def main(argv=None):

@@ -123,8 +123,7 @@ class GraphedStep:
         return loss
 
     def _sync_and_step(self):
-        self.sync.on_ready([(p, p.grad) for p in self.net.parameters() if p.grad is not None])
-        self.sync.finish()
+        self.sync.reduce_all([(p, p.grad) for p in self.net.parameters() if p.grad is not None])
         self.opt.step()
 
     def __call__(self, lr):
@@ -145,6 +144,12 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=DEFAULTS["num_epochs"])
     ap.add_argument("--iters-per-epoch", type=int, default=20, help="synthetic data: iterations per epoch")
     ap.add_argument("--save-dir", default=None)
+    ap.add_argument("--pretrained", default=None, help="ImageNet state_dict file (torchvision keys) for the by-name "
+                                                       "initialisation of train.py:59-78; no network access here")
+    ap.add_argument("--resume", default=None, help="checkpoint written by this script or by the reference")
+    ap.add_argument("--loader", action="store_true",
+                    help="feed every step from a DataLoader (synthetic yoloDataset, 4 workers as train.py:119) through "
+                         "the device prefetcher + device target encoder instead of one resident batch")
     args = ap.parse_args(argv)
     from . import distributed as ydist
     from .utils.YOLODataLoader import synthetic_batch
@@ -156,16 +161,35 @@ def main(argv=None):
     logger = create_logger(base, 'train') if rank == 0 else None
     net, loss_layer, opt = build(args.backbone, args.S, DEFAULTS["B"], DEFAULTS["clsN"], bs, device, logger=logger,
                                  quiet=rank != 0)
+    if args.pretrained or args.resume:
+        from . import checkpoint
+        if args.pretrained:
+            taken = checkpoint.init_from_pretrained(net, torch.load(args.pretrained, map_location='cpu', weights_only=True))
+            if logger:
+                logger.info('initialised %d tensors by name from %s' % (len(taken), args.pretrained))
+        if args.resume:
+            checkpoint.load(net, args.resume, device)
     sync = ydist.GradSync(net) if world > 1 else None
     images, target = synthetic_batch(bs, args.S, seed=1234 + rank, device=device)
+    feed = None
+    if args.loader:
+        from torch.utils.data import DataLoader
+        from .utils.YOLODataLoader import DevicePrefetcher, collate_raw, yoloDataset
+        ds = yoloDataset(None, S=args.S, B=DEFAULTS["B"], C=DEFAULTS["clsN"], raw_targets=True, seed=1234 + rank,
+                         length=bs * args.iters_per_epoch)
+        feed = DevicePrefetcher(DataLoader(ds, batch_size=bs, shuffle=True, num_workers=4, collate_fn=collate_raw,
+                                           drop_last=True), device, args.S, DEFAULTS["B"], DEFAULTS["clsN"])
     lr, it = DEFAULTS["learning_rate"], 0
     for epoch in range(args.epochs):
         if logger:
             logger.info('\n\nStarting epoch %d / %d' % (epoch + 1, args.epochs))
             logger.info('Learning Rate for this epoch: {}'.format(opt.param_groups[0]['lr']))
         total_loss, t_epoch = 0., time.perf_counter()
+        batches = iter(feed) if feed is not None else None
         for i in range(args.iters_per_epoch):
             t0 = time.perf_counter()
+            if batches is not None:
+                images, target = next(batches)
             it += 1
             lr = learning_rate_policy(it, epoch, lr, DEFAULTS["lr_adjust_map"])
             loss = train_step(net, loss_layer, opt, images, target, lr, sync)
@@ -181,8 +205,8 @@ def main(argv=None):
                                                                               (time.perf_counter() - t_epoch) / 60))
         if rank == 0:
             os.makedirs(base, exist_ok=True)
-            sd = {'module.' + k: v for k, v in net.state_dict().items()}    # nn.DataParallel key prefix (train.py:80,:209)
-            torch.save(sd, '%s/%s_%s_S%d_yolo.pth' % (base, args.backbone, opt_name, args.S))
+            from . import checkpoint                                       # nn.DataParallel key prefix (train.py:80,:209)
+            checkpoint.save(net, '%s/%s_%s_S%d_yolo.pth' % (base, args.backbone, opt_name, args.S))
 
 
 if __name__ == "__main__":

@@ -10,7 +10,10 @@
     ``cls cx cy w h`` rows, reference :94-106): boxes/labels are read and encoded; image decoding
     and the imgaug pipeline (:31-79, :161-172) need cv2/imgaug and are out of scope here, so an
     ``image_loader`` callable must be supplied for real images.
-The encoder is host code, as in the reference (it runs in DataLoader worker processes).
+``encode_boxes`` is host code, as in the reference (it runs in DataLoader worker processes);
+``encode_targets_device`` is the same encoder as one HIP kernel over a whole batch, and
+``DevicePrefetcher`` feeds the training loop: pinned staging buffers, H2D copies and the device encoder on a
+copy stream, one batch ahead of the step that is running.
 """
 import math
 
@@ -43,12 +46,122 @@ def encode_boxes(boxes, labels, S, B=2, C=20):
     return target
 
 
+def collate_raw(samples):
+    """DataLoader ``collate_fn`` for ``yoloDataset(raw_targets=True)``: images stacked, boxes/labels padded to the
+    largest count of the batch -> (images [N,3,H,W], boxes [N,Kmax,4], labels [N,Kmax] int64, counts [N] int32[, fnames])."""
+    imgs = torch.stack([s[0] for s in samples])
+    counts = torch.tensor([int(s[1].shape[0]) for s in samples], dtype=torch.int32)
+    kmax = max(1, int(counts.max()) if len(samples) else 1)
+    boxes = torch.zeros((len(samples), kmax, 4), dtype=torch.float32)
+    labels = torch.zeros((len(samples), kmax), dtype=torch.int64)
+    for i, s in enumerate(samples):
+        k = int(counts[i])
+        if k:
+            boxes[i, :k] = torch.as_tensor(s[1], dtype=torch.float32).reshape(-1, 4)
+            labels[i, :k] = torch.as_tensor(s[2], dtype=torch.int64).reshape(-1)
+    out = (imgs, boxes, labels, counts)
+    if len(samples) and len(samples[0]) > 3:
+        out = out + ([s[3] for s in samples],)
+    return out
+
+
+def encode_targets_device(boxes, labels, counts, S, B=2, C=20, out=None, check=True):
+    """The reference encoder (:200-230) for a whole batch on the GPU: boxes [N,K,4] fp32, labels [N,K] int64,
+    counts [N] int32 (device tensors) -> target [N,S,S,B*5+C] fp32, bit-identical to ``encode_boxes`` per image.
+    ``check`` reads back the out-of-grid flag (one host sync) and raises IndexError like the reference would."""
+    from .._lib import check as _check, lib, ptr, require_cuda, stream_ptr
+    require_cuda(boxes, labels, counts)
+    N, K = int(boxes.shape[0]), int(boxes.shape[1])
+    if boxes.dtype != torch.float32 or labels.dtype != torch.int64 or counts.dtype != torch.int32:
+        raise TypeError("encode_targets_device: boxes fp32, labels int64, counts int32")
+    if tuple(labels.shape) != (N, K) or tuple(boxes.shape) != (N, K, 4) or tuple(counts.shape) != (N,):
+        raise ValueError("encode_targets_device: boxes [N,K,4], labels [N,K], counts [N]")
+    boxes, labels, counts = boxes.contiguous(), labels.contiguous(), counts.contiguous()
+    if out is None:
+        out = torch.empty((N, S, S, B * 5 + C), dtype=torch.float32, device=boxes.device)
+    elif tuple(out.shape) != (N, S, S, B * 5 + C) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("encode_targets_device: out must be a contiguous fp32 [N,S,S,B*5+C] tensor")
+    err = torch.empty(1, dtype=torch.int32, device=boxes.device)
+    _check(lib().yv1_encode_targets(ptr(boxes), ptr(labels), ptr(counts), N, K, S, B, C, ptr(out), ptr(err),
+                                    stream_ptr(boxes.device)), "yv1_encode_targets")
+    if check and int(err.item()) != 0:
+        raise IndexError("encode_targets_device: a box centre falls outside the %dx%d grid or a label outside [0,%d)"
+                         % (S, S, C))
+    return out
+
+
+class DevicePrefetcher:
+    """Wraps an iterable of host batches -- ``(images, boxes, labels, counts)`` from ``collate_raw`` or
+    ``(images, target)`` -- and yields device ``(images, target)`` pairs.  Batch t+1 is staged through pinned
+    memory, copied and encoded on a copy stream while step t runs; the consumer's stream waits on an event, never
+    on the host.  Two staging slots, so a pinned buffer is not rewritten while its copy may still be in flight."""
+
+    def __init__(self, loader, device, S, B=2, C=20, out_images=None, out_target=None):
+        self.loader, self.device, self.S, self.B, self.C = loader, torch.device(device), S, B, C
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.static = (out_images, out_target)      # optional static destination buffers (hipGraph replay)
+        self._pinned = [{}, {}]
+        self._slot_done = [None, None]
+
+    def _pin(self, slot, name, t):
+        buf = self._pinned[slot].get(name)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._pinned[slot][name] = buf
+        buf.copy_(t)
+        return buf
+
+    def _stage(self, batch, slot):
+        if self._slot_done[slot] is not None:
+            self._slot_done[slot].synchronize()      # the copy that last read this slot's pinned buffers is done
+        names = ("images", "boxes", "labels", "counts") if len(batch) >= 4 else ("images", "target")
+        host = [self._pin(slot, n, t) for n, t in zip(names, batch)]
+        with torch.cuda.stream(self.copy_stream):
+            dev = [h.to(self.device, non_blocking=True) for h in host]
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+            self._slot_done[slot] = done
+            if len(dev) >= 4:
+                target = encode_targets_device(dev[1], dev[2], dev[3], self.S, self.B, self.C, check=False)
+            else:
+                target = dev[1]
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        return dev[0], target, ready
+
+    def __iter__(self):
+        it = iter(self.loader)
+        slot = 0
+        try:
+            nxt = self._stage(next(it), slot)
+        except StopIteration:
+            return
+        while nxt is not None:
+            images, target, ready = nxt
+            slot ^= 1
+            try:
+                nxt = self._stage(next(it), slot)
+            except StopIteration:
+                nxt = None
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ready)
+            images.record_stream(cur)
+            target.record_stream(cur)
+            if self.static[0] is not None:
+                self.static[0].copy_(images)
+                self.static[1].copy_(target)
+                yield self.static
+            else:
+                yield images, target
+
+
 class yoloDataset(data.Dataset):
     image_size = 448
 
     def __init__(self, list_file=None, train=True, transform=None, device='cpu', little_train=False,
                  with_file_path=False, S=7, B=2, C=20, test_mode=False, synthetic=None, length=512, objs=3,
-                 seed=1234, image_loader=None, image_size=None):
+                 seed=1234, image_loader=None, image_size=None, raw_targets=False):
+        self.raw_targets = raw_targets            # True: return (img, boxes, labels): the batch is encoded on the GPU
         self.train = train
         self.transform = transform
         self.S, self.B, self.C = S, B, C
@@ -122,6 +235,8 @@ class yoloDataset(data.Dataset):
             if self.transform is not None:
                 img = self.transform(img)
             boxes, labels = self.get_boxes_labels(fname)
+        if self.raw_targets:
+            return (img, boxes, labels, fname) if self.with_file_path else (img, boxes, labels)
         target = self.encoder(boxes, labels)
         if self.with_file_path:
             return img, target, fname
