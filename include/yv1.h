@@ -48,6 +48,25 @@ int yv1_scale_by_device_scalar(float* x, const float* scalar, long long n, yv1_s
 int yv1_decode_nms_batched(const float* pred, int N, int S, int B, int C, double thresh, float nms_th, float* out_boxes,
                            long long* out_cls, float* out_scores, long long* out_keep_idx, int* out_counts,
                            int* out_ncand, yv1_stream_t stream);
+/* ---- FP8 (OCP e4m3) inference convolution: BASELINE config 5 ------------------------------------------ */
+/* conv + folded eval-mode BatchNorm + residual + ReLU in one launch (OriginResNet.py:87-107 in eval mode):
+ *   t = bf16(acc * alpha[c] + beta[c]);  out = relu?(t + residual);  y_bf16 = bf16(out), y_fp8 = e4m3(clamp(bf16(out)))
+ * x8 [N,IH,IW,*] e4m3 (pixel stride ldx bytes), w8 [Cout][k*k][Cin] e4m3 from yv1_prep_weights_fp8, residual /
+ * y_bf16 bf16 with pixel strides ldr / ld16, y_fp8 e4m3 with pixel stride ld8; either output may be NULL.
+ * Cin % 64 == 0, Cout % 32 == 0.  MFMA: v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales. */
+int yv1_conv2d_fwd_nhwc_fp8(const void* x8, const void* w8, const float* alpha, const float* beta, const void* residual,
+                            int ldr, void* y_bf16, int ld16, void* y_fp8, int ld8, int N, int IH, int IW, int ldx, int Cin,
+                            int Cout, int k, int stride, int pad, int relu, yv1_stream_t stream);
+/* bf16 NHWC -> e4m3 NHWC (saturating at +-448), C % 8 == 0 */
+int yv1_quantize_bf16_to_fp8(const void* x, int ldx, void* y8, int ldy, long long npix, int C, yv1_stream_t stream);
+/* fp32 OIHW (element strides so,si,sh,sw) -> e4m3 [Opad][k*k][Ipad]; q[o] (Opad floats) = the power of two each
+ * output channel was multiplied by before rounding (largest with amax*q <= 448; 1 for all-zero / padded rows) */
+int yv1_prep_weights_fp8(const float* w, long long so, long long si, long long sh, long long sw, int O, int I, int k,
+                         int Opad, int Ipad, void* w8, float* q, yv1_stream_t stream);
+/* alpha[c] = scale[c] / q[c], beta[c] = shift[c] for c < C, zero up to Cpad (scale/shift NULL = 1 / 0) */
+int yv1_fp8_fold_bn(const float* scale, const float* shift, const float* q, int C, int Cpad, float* alpha, float* beta,
+                    yv1_stream_t stream);
+
 /* ---- target encoder: utils/YOLODataLoader.py:200-230 for a whole batch -------------------------------- */
 /* boxes [N][Kmax][4] fp32 normalised (cx,cy,w,h), labels [N][Kmax] int64, counts [N] (boxes used per image).
  * target [N][S][S][B*5+C] fp32 is written completely (zeros where no box lands).  Later boxes replace earlier

@@ -32,6 +32,12 @@ SIGNATURES = {
     "yv1_nms": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p, c_p]),
     "yv1_iou_matrix": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
     "yv1_convert_cxcywh_to_xyxy": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    # conv_fp8.hip
+    "yv1_conv2d_fwd_nhwc_fp8": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                      c_i, c_i, c_i, c_p]),
+    "yv1_quantize_bf16_to_fp8": (c_i, [c_p, c_i, c_p, c_i, c_ll, c_i, c_p]),
+    "yv1_prep_weights_fp8": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "yv1_fp8_fold_bn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     # conv.hip
     "yv1_conv2d_fwd_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "yv1_conv2d_stem_fwd_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),

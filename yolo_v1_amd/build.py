@@ -21,6 +21,7 @@ SOURCES = {
     "decode_nms.hip": ["-ffp-contract=off"],
     "encode.hip": ["-ffp-contract=off"],
     "conv.hip": [],
+    "conv_fp8.hip": [],
     "wgrad.hip": [],
     "elementwise.hip": [],
     "optim.hip": [],
