@@ -256,6 +256,56 @@ def test_graphed_step_is_bitwise_the_eager_step():
         assert torch.equal(a(images), b(images))
 
 
+def test_data_parallel_graphed_step_two_graphs_is_bitwise_the_eager_step():
+    """The multi-rank form of GraphedStep (two hipGraphs cut inside the backward pass, RCCL collective of the first
+    phase's gradients issued between them, second collective + optimizer after) rehearsed with a process group of ONE
+    rank: averaging over one rank is the identity, so losses and weights must be bit-identical to the eager step; the
+    single-graph fallback (YV1_DP_PHASES=1 / executors without a phase boundary) likewise."""
+    import torch.distributed as dist
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    from yolo_v1_amd.distributed import GradSync
+    from yolo_v1_amd.optim import FusedSGD
+    from yolo_v1_amd.train import GraphedStep, train_step
+    from yolo_v1_amd.utils.YOLODataLoader import synthetic_batch
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device(DEV))
+    try:
+        images, target = synthetic_batch(4, 2, hw=128, device=DEV)
+        lrs = [1e-3, 2e-3, 5e-4, 1e-3]
+        torch.manual_seed(0)
+        a = resnet50(S=7).to(DEV).train()
+        init = {k: v.clone() for k, v in a.state_dict().items()}
+        oa = FusedSGD(a.parameters(), lr=0.0, momentum=0.99)
+        la = YOLOLossV1(4, 2, 2, 20, _quiet=True)
+        ref = [train_step(a, la, oa, images, target, lr).item() for lr in lrs]
+        for two_phase in (True, False):
+            b = resnet50(S=7).to(DEV).train()
+            b.load_state_dict(init)
+            ob_ = FusedSGD(b.parameters(), lr=0.0, momentum=0.99)
+            for grp in ob_.param_groups:
+                grp['lr'] = lrs[0]
+            sync = GradSync(b)
+            gs = GraphedStep(b, YOLOLossV1(4, 2, 2, 20, _quiet=True), ob_, images, target, sync, warmup=1,
+                             two_phase=two_phase)
+            assert gs.two_phase == two_phase and (gs.phase1 is not None) == two_phase
+            if two_phase:      # head + layer5 + layer4: most of the gradient bytes
+                early = sum(g.numel() for _, g in gs.phase1)
+                assert 0.7 < early / sum(p.numel() for p in b.parameters()) < 0.9
+            got = [gs(lr).item() for lr in lrs[1:]]
+            assert got == ref[1:], (two_phase, got, ref[1:])
+            pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+            for k in ("conv1.weight", "layer1.0.conv1.weight", "layer4.0.downsample.0.weight", "layer5.2.bn3.weight",
+                      "bn_end.bias"):
+                assert torch.equal(pa[k], pb[k]), (two_phase, k)
+            assert sync.buckets_issued == 1 + (2 if two_phase else 1) * (len(lrs) - 1)     # eager warm-up + replays
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_batched_eval_loop_matches_per_image_oracle_pipeline():
     """run_test_mAP (batched forward + batched GPU decoder/NMS + host voc_eval) against the reference's
     per-image pipeline restated with the oracle decoder and oracle voc_eval on the same network outputs."""

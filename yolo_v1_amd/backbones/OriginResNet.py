@@ -150,6 +150,7 @@ class ResNet(HipBackbone):
         # weight gradients overlap with the dgrad / BN chain on a side stream, unless a gradient-ready hook
         # (overlapped RCCL all-reduce issued from the main stream) needs them in main-stream order
         side = ops.SideStream(dev, enabled=self._grad_ready_hook is None and self.wgrad_side_stream)
+        boundary_blk = self.layer4[0]                 # see HipBackbone.set_phase_boundary
         wh = self.cw(self.layer6)
         dyh = ops.new_act(N, yh.H, yh.W, wh.Opad, dev)
         dg, db = ops.head_bwd(gpred, pred, yh, sh, self.bn_end, dyh)
@@ -191,6 +192,9 @@ class ResNet(HipBackbone):
                 ops.conv_dgrad(dy1, w1, g_in, accumulate=True)
             self._emit(grads, list(blk.parameters()))
             g = g_in
+            if self._phase_boundary is not None and blk is boundary_blk:
+                side.join()
+                self._phase_boundary(grads)
 
         xp, y0, s0, z0, H, W, pidx = rec["stem"]
         w0 = self.cw(self.conv1, stem=True)

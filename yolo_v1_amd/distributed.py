@@ -68,6 +68,13 @@ class GradSync:
         if self.pending_bytes >= self.bucket_bytes:
             self._flush()
 
+    def start(self, pairs):
+        """Issue one asynchronous collective for ``pairs`` now (whatever the bucket size); ``finish()`` /
+        ``reduce_all()`` later waits for it."""
+        self.pending.extend(pairs)
+        self.pending_bytes += sum(g.numel() * g.element_size() for _, g in pairs)
+        self._flush()
+
     def reduce_all(self, pairs):
         """Everything in ONE collective (nothing left to overlap with: used after a hipGraph replay of
         forward+backward, where one large message runs the xGMI links at their best rate)."""

@@ -77,6 +77,7 @@ class HipBackbone(nn.Module):
         super().__init__()
         self._convw = {}      # ConvParam -> ops.ConvWeights
         self._grad_ready_hook = None
+        self._phase_boundary = None
         self.wgrad_side_stream = os.environ.get("YV1_WGRAD_SIDE_STREAM", "1") != "0"
 
     def set_grad_ready_hook(self, fn):
@@ -84,6 +85,13 @@ class HipBackbone(nn.Module):
         kernels producing those parameter gradients have been launched (used by distributed.GradSync
         to overlap the all-reduce with the rest of the backward)."""
         self._grad_ready_hook = fn
+
+    def set_phase_boundary(self, fn):
+        """``fn(grads_so_far)`` is called ONCE from inside the backward executor, at the point where the deep, parameter-
+        heavy stages are done (ResNet: head, layer5, layer4 = 79 % of the gradient bytes after ~10 % of the backward
+        time) and every kernel launched so far has been joined back onto the main stream.  train.GraphedStep ends its
+        first hipGraph there, so the RCCL all-reduce of those gradients runs beside the replay of the second graph."""
+        self._phase_boundary = fn
 
     def _emit(self, grads, params):
         if self._grad_ready_hook is not None:

@@ -72,6 +72,34 @@ class YOLOLossV1(nn.Module):
         self.quiet = _quiet
         self.last_components = None   # device tensor [4]: location, contain, not-contain, classify (raw sums)
 
+    def loss_and_grad(self, pred_tensor, target_tensor):
+        """(total loss, d total / d pred) from the one fused launch, without an autograd graph -- what
+        ``forward`` + ``backward`` produce, for executors that drive the backward pass themselves
+        (train.GraphedStep with several ranks)."""
+        _lib.require_cuda(pred_tensor, target_tensor)
+        pred = pred_tensor.detach()
+        if pred.dtype != torch.float32:
+            pred = pred.float()
+        target = target_tensor.to(dtype=torch.float32).contiguous()
+        N, D = pred.shape[0], self.B * 5 + self.C
+        if tuple(pred.shape) != (N, self.S, self.S, D) or tuple(target.shape) != (N, self.S, self.S, D):
+            raise _lib.Yv1Error("loss expects [N,%d,%d,%d] tensors, got %s and %s"
+                                % (self.S, self.S, D, tuple(pred.shape), tuple(target.shape)))
+        L = _lib.lib()
+        dev = pred.device
+        ws_bytes = L.yv1_loss_workspace_bytes(N, self.S)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        comps = torch.empty(4, dtype=torch.float32, device=dev)
+        grad = torch.empty((N, self.S, self.S, D), dtype=torch.float32, device=dev)
+        st = pred.stride()
+        _lib.check(L.yv1_loss_fwd_bwd(_lib.ptr(pred), st[0], st[1], st[2], st[3], _lib.ptr(target), N, self.S, self.B,
+                                      self.C, float(self.lambda_coord), float(self.lambda_noobj), float(self.batch_size),
+                                      _lib.ptr(loss), _lib.ptr(comps), _lib.ptr(grad), _lib.ptr(ws), ws_bytes,
+                                      _lib.stream_ptr(dev)), "yv1_loss_fwd_bwd")
+        self.last_components = comps
+        return loss, grad
+
     def forward(self, pred_tensor, target_tensor):
         comps = torch.empty(4, dtype=torch.float32, device=pred_tensor.device)
         total = _LossFn.apply(pred_tensor, target_tensor, self.S, self.B, self.C, float(self.lambda_coord),
