@@ -75,7 +75,16 @@ def _gloo_worker(rank, world, port, q):
         p.grad = g.clone()
         sync.on_ready([(p, g)])
     sync.finish()
-    q.put((rank, [g.clone() for g in grads], [p.grad.clone() for p in params], sync.buckets_issued))
+    first = [p.grad.clone() for p in params]
+    # the sequence of the two-graph data-parallel step: early gradients start their collective, the rest follow in
+    # reduce_all, which also waits for the early one
+    for p, g in zip(params, grads):
+        p.grad = g.clone()
+    sync2 = GradSync(None)
+    sync2.start([(params[0], params[0].grad)])
+    sync2.reduce_all([(p, p.grad) for p in params[1:]])
+    second = [p.grad.clone() for p in params]
+    q.put((rank, [g.clone() for g in grads], first, sync.buckets_issued, second, sync2.buckets_issued))
     dist.destroy_process_group()
 
 
@@ -91,12 +100,14 @@ def test_gradsync_gloo_world2_averages_into_param_grad():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, g0, out0, nb0), (_, g1, out1, nb1) = res
-    assert nb0 >= 2 and nb0 == nb1
-    for a, b, o0, o1 in zip(g0, g1, out0, out1):
+    (_, g0, out0, nb0, sec0, nc0), (_, g1, out1, nb1, sec1, nc1) = res
+    assert nb0 >= 2 and nb0 == nb1 and nc0 == nc1 == 2
+    for a, b, o0, o1, s0, s1 in zip(g0, g1, out0, out1, sec0, sec1):
         want = (a + b) / 2
         torch.testing.assert_close(o0, want)
         torch.testing.assert_close(o1, want)
+        torch.testing.assert_close(s0, want)
+        torch.testing.assert_close(s1, want)
 
 
 def test_checkpoint_roundtrip_and_pretrained_by_name(tmp_path):
