@@ -274,7 +274,7 @@ def _shrink_partials(part, rows, W, dev):
     """Pre-reduction of very long partial tables (the finalize kernels sum up to ~2k rows themselves)."""
     if rows <= 2048:
         return part, rows
-    RB = (rows + 31) // 32
+    RB = (rows + 255) // 256                    # 256 x (W/128) workgroups: enough to stream the table at HBM rate
     r2 = (rows + RB - 1) // RB
     out = _f32(r2 * W, dev)
     check(lib().yv1_reduce_rows(ptr(part), ptr(out), rows, W, RB, stream_ptr(dev)), "yv1_reduce_rows")
