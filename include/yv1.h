@@ -95,6 +95,12 @@ int yv1_pack_input_nhwc4(const float* x_nchw, void* y, int N, int H, int W, yv1_
  * pixels of dx are written (accumulate into a dx the main path already wrote). */
 int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin, int Cout,
                                int lddy, int k, int stride, int pad, int accumulate, yv1_stream_t stream);
+/* 1x1 stride-1 dgrad with the identity shortcut's gradient folded into the epilogue (OriginResNet.py:104-105
+ * backward): dx = dgrad(dy, wt) + (relu_mask bit ? g : 0); g [N,IH,IW,*] bf16 with pixel stride ldg, relu_mask
+ * the [pixels][ldmask]-byte 1-bit mask yv1_bn_apply wrote for that block output. */
+int yv1_conv2d_dgrad_add_masked_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx,
+                                          int Cin, int Cout, int lddy, const void* g, int ldg, const void* relu_mask,
+                                          int ldmask, yv1_stream_t stream);
 /* dw fp32 [Cout][k*k][Cin] (= channels_last storage of the OIHW gradient) */
 size_t yv1_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int k);
 int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx, int Cin, int Cout,

@@ -288,3 +288,30 @@ def test_stem_chain_backward():
     close(to_nchw(dy0), y0r.grad, rtol=2e-2, scale_atol=2e-2)
     np.testing.assert_allclose(dg.cpu().numpy(), ref_bn.weight.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.weight.grad.abs().max()))
     np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout", [(2, 16, 16, 256, 64), (3, 14, 14, 512, 128), (2, 7, 9, 2048, 512), (64, 28, 28, 256, 64)])
+def test_conv_dgrad_add_masked_equals_two_step_path(N, H, Wd, Cin, Cout):
+    """Identity-shortcut gradient folded into conv1's dgrad epilogue: bit-identical to materialising the masked
+    gradient and accumulating into it (what the backward did before), and equal to fp32 math within bf16 rounding."""
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(N + Cin)
+    w = bf(torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5)
+    wm = W(w, 1, 1, 0)
+    dy = bf(torch.randn(N, wm.cw.Opad, H, Wd, generator=g))
+    dy[:, Cout:] = 0
+    gout = bf(torch.randn(N, Cin, H, Wd, generator=g))
+    bits = torch.randint(0, 256, (N * H * Wd, Cin // 8), generator=g, dtype=torch.int64).to(torch.uint8)
+    dya, ga = nhwc_act(dy), nhwc_act(gout)
+    mask = ops.ReluMask(N * H * Wd, Cin, DEV)
+    mask.t.copy_(bits.to(DEV))
+    dx_new = ops.new_act(N, H, Wd, Cin, DEV)
+    ops.conv_dgrad_add_masked(dya, wm.cw, dx_new, ga, mask)
+    # two-step path: masked copy, then accumulate
+    m = ((bits.unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(N, H, Wd, Cin).permute(0, 3, 1, 2).bool()
+    dres = nhwc_act(torch.where(m, gout, torch.zeros_like(gout)))
+    ops.conv_dgrad(dya, wm.cw, dres, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dx_new.t, dres.t)
+    ref = F.conv_transpose2d(dy[:, :Cout], w) + torch.where(m, gout, torch.zeros_like(gout))
+    close(to_nchw(dx_new), ref, rtol=2e-2, scale_atol=2e-2)

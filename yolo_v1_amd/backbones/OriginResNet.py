@@ -172,8 +172,9 @@ class ResNet(HipBackbone):
                 grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
                 grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side)
             else:
-                # identity shortcut: the masked gradient is also the shortcut's contribution to g_in
-                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask, dres=g_in)
+                # identity shortcut: its contribution to g_in (g where the block output was positive) is added in
+                # the epilogue of conv1's dgrad below
+                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
             grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side)
             dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
             ops.conv_dgrad(dy3, w3, dz2)
@@ -189,7 +190,7 @@ class ResNet(HipBackbone):
                 ops.conv_dgrad(dy1, w1, g_in, accumulate=False)
                 ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate
             else:
-                ops.conv_dgrad(dy1, w1, g_in, accumulate=True)
+                ops.conv_dgrad_add_masked(dy1, w1, g_in, g, omask)
             self._emit(grads, list(blk.parameters()))
             g = g_in
             if self._phase_boundary is not None and blk is boundary_blk:

@@ -53,6 +53,9 @@ struct ConvArgs {
   int wr0, wrs, ws0, wss, WS;   // weight tap of loop tap (r,s): (wr0 + r*wrs)*WS + (ws0 + s*wss)
   int Kw;                       // elements per weight row (= all filter taps x Cin)
   int accumulate;
+  const bf16_t* AS;             // optional: out += AM-bit ? AS[m][n] : 0 (shortcut gradient through a ReLU, see
+  const unsigned char* AM;      //           yv1_conv2d_dgrad_add_masked_nhwc_bf16); AM is [M][ldam] bytes, bit k of
+  int ldas, ldam;               //           byte j = channel 8j+k
   int M;
   int MT, NT;
   int dbg;             // tuning only: bit0 skip the in-loop global loads / LDS stores, bit1 skip the MFMA block
@@ -309,6 +312,21 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_g
         off = ((size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0) * a.ldy + n0 + cc * 8;
       }
       uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
+      if (a.AS) {
+        const uint4 o = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + n0 + cc * 8);
+        const unsigned mb = a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)];
+        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+        const unsigned* po = reinterpret_cast<const unsigned*>(&o);
+        unsigned res[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = __uint_as_float(pv[k] << 16) + (((mb >> (2 * k)) & 1u) ? __uint_as_float(po[k] << 16) : 0.f);
+          const float hi = __uint_as_float(pv[k] & 0xffff0000u) +
+                           (((mb >> (2 * k + 1)) & 1u) ? __uint_as_float(po[k] & 0xffff0000u) : 0.f);
+          res[k] = pack_bf16x2(lo, hi);
+        }
+        v = make_uint4(res[0], res[1], res[2], res[3]);
+      }
       if (a.accumulate) {
         const uint4 o = *reinterpret_cast<const uint4*>(a.Y + off);
         const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
@@ -436,6 +454,7 @@ extern "C" int yv1_conv2d_fwd_nhwc_bf16(const void* x, const void* w, void* y, i
                                         hipStream_t stream) {
   if (!x || !w || !y || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   ConvArgs a;
+  a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
   a.X = (const bf16_t*)x; a.W = (const bf16_t*)w; a.Y = (bf16_t*)y; a.stats = stats;
   a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx;
   a.P = (IH + 2 * pad - k) / stride + 1; a.Q = (IW + 2 * pad - k) / stride + 1;
@@ -453,6 +472,7 @@ extern "C" int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, 
                                         float* stats, hipStream_t stream) {
   if (!xp || !w || !y || N <= 0 || (H & 1) || (W & 1)) return YV1_ERR_BAD_ARG;
   ConvArgs a;
+  a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
   a.X = (const bf16_t*)xp; a.W = (const bf16_t*)w; a.Y = (bf16_t*)y; a.stats = stats;
   a.N = N; a.IH = H + 6; a.IW = W + 6; a.ldx = 4;       // "pixel" = 4 elements; one tap row = 32 contiguous elements
   a.P = H / 2; a.Q = W / 2;
@@ -480,6 +500,7 @@ extern "C" int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* 
   if (stride != 1 && stride != 2) return YV1_ERR_UNSUPPORTED;
   const int OH = (IH + 2 * pad - k) / stride + 1, OW = (IW + 2 * pad - k) / stride + 1;
   ConvArgs a;
+  a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
   a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx; a.stats = nullptr;
   a.N = N; a.IH = OH; a.IW = OW; a.ldx = lddy;
   a.Cin = Cout; a.Cout = Cin; a.R = k; a.S = k;
@@ -514,6 +535,28 @@ extern "C" int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* 
   a.P = IH; a.Q = IW; a.os = 1;
   a.ah = 1; a.bh = -1; a.ch = pad; a.aw = 1; a.bw = -1; a.cw = pad; a.log2d = (stride == 2) ? 1 : 0;
   a.M = N * a.P * a.Q;
+  return dispatch(a, stream);
+}
+
+// 1x1 stride-1 data gradient of the first convolution of an identity-shortcut Bottleneck, with the shortcut's own
+// gradient folded into the epilogue:  dx = dgrad(dy, wt) + (relu_mask ? g : 0)  (OriginResNet.py:104-105 backward:
+// out = relu(bn3(..) + x) hands x the gradient g where the output was positive).  g: [N,IH,IW,*] bf16 (pixel stride
+// ldg), relu_mask: the 1-bit-per-element mask yv1_bn_apply wrote for that block output ([pixels][ldmask] bytes).
+extern "C" int yv1_conv2d_dgrad_add_masked_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW,
+                                                     int lddx, int Cin, int Cout, int lddy, const void* g, int ldg,
+                                                     const void* relu_mask, int ldmask, hipStream_t stream) {
+  if (!dy || !wt || !dx || !g || !relu_mask || N <= 0) return YV1_ERR_BAD_ARG;
+  if (ldg % 8 || Cin % 8) return YV1_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx; a.stats = nullptr;
+  a.N = N; a.IH = IH; a.IW = IW; a.ldx = lddy;
+  a.Cin = Cout; a.Cout = Cin; a.R = 1; a.S = 1;
+  a.OH = IH; a.OW = IW; a.ldy = lddx; a.accumulate = 0;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = 1; a.Kw = Cout;
+  a.P = IH; a.Q = IW; a.os = 1;
+  a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
+  a.M = N * a.P * a.Q;
+  a.AS = (const bf16_t*)g; a.ldas = ldg; a.AM = (const unsigned char*)relu_mask; a.ldam = ldmask;
   return dispatch(a, stream);
 }
 

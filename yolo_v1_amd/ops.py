@@ -177,6 +177,20 @@ def conv_dgrad(dy, w, dx, accumulate=False):
           "yv1_conv2d_dgrad_nhwc_bf16")
 
 
+def conv_dgrad_add_masked(dy, w, dx, g, mask):
+    """dx = conv_transpose(dy, w) + (mask ? g : 0) for the 1x1 stride-1 first convolution of an identity-shortcut
+    block: the shortcut's gradient (block-output gradient ``g`` gated by the block's ReLU ``mask``) is added in the
+    GEMM epilogue instead of being materialised and read-modify-written."""
+    if w.k != 1 or w.stride != 1 or w.pad != 0:
+        raise ValueError("conv_dgrad_add_masked: 1x1 stride-1 convolution only")
+    if (g.N, g.H, g.W, g.C) != (dx.N, dx.H, dx.W, dx.C):
+        raise ValueError("conv_dgrad_add_masked: g must have dx's geometry")
+    dev = dy.t.device
+    check(lib().yv1_conv2d_dgrad_add_masked_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld,
+                                                      g.p, g.ld, mask.p, mask.ld, stream_ptr(dev)),
+          "yv1_conv2d_dgrad_add_masked_nhwc_bf16")
+
+
 class SideStream:
     """Runs leaf work (weight gradients: nothing else in the backward consumes them) on a second HIP stream so it
     overlaps with the dgrad / BatchNorm chain on the main stream -- eagerly and inside a captured hipGraph
