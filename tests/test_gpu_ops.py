@@ -62,6 +62,10 @@ CONV_CASES = [
     (2, 7, 7, 2048, 30, 1, 1, 0),       # head (Cout padded to 32)
     (9, 28, 28, 128, 128, 3, 1, 1),     # enough tiles for the 128x128 kernel
     (8, 56, 56, 64, 256, 1, 1, 0),
+    # 3x3 stride-1: the multi-tap weight-gradient kernel (32-pixel row segments; ragged rows; 16-pixel segments)
+    (2, 20, 40, 64, 64, 3, 1, 1),
+    (3, 13, 25, 256, 128, 3, 1, 1),
+    (1, 33, 57, 128, 192, 3, 1, 1),
 ]
 
 
