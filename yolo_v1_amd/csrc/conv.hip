@@ -74,6 +74,132 @@ __device__ __forceinline__ int swz(int row, int chunk) {
   return chunk ^ ((row / (16 / CPR)) % CPR);  // conflict-free for the 32x32x16 fragment reads
 }
 
+// Shared epilogue of the GEMM kernels: BatchNorm statistic partials from the fp32 accumulators, DPP lane swap +
+// packed rounding into a bf16 LDS tile, full-line stores (optionally accumulating / adding the masked shortcut
+// gradient).  The caller has finished its last LDS read (barrier) before the tile overwrites the staging buffers.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const ConvArgs& a,
+                                              unsigned char* smem, int m0, int n0, int mt) {
+  constexpr int NTH = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;   // bytes; pitch/4 % 32 == 16
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // ---- epilogue 1: BatchNorm batch statistics from the fp32 accumulators
+  // C/D layout of 32x32: col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel)
+  float* red = reinterpret_cast<float*>(smem + BM * EPI_PITCH);   // [WM][2][BN] floats, after the epilogue tile
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][j][e];
+          s += v;
+          ss += v * v;
+        }
+      s += __shfl_xor(s, 32, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lh == 0) {
+        const int c = wn * (BN / WN) + j * 32 + l31;
+        red[(wm * 2 + 0) * BN + c] = s;
+        red[(wm * 2 + 1) * BN + c] = ss;
+      }
+    }
+  }
+
+  // ---- epilogue 2: accumulators -> bf16 tile in LDS.  A lane holds ONE channel (column) of 16 pixel rows;
+  // neighbouring lanes swap one value (DPP quad_perm, no LDS traffic) so each lane owns a 2-channel pair,
+  // rounded by v_cvt_pk_bf16_f32 and written as one dword.
+  unsigned char* et = smem;
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * (BN / WN) + j * 32 + l31;
+      const int rbase = wm * (BM / WM) + i * 32 + 4 * lh;
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const float mine_lo = acc[i][j][e], mine_hi = acc[i][j][e + 1];
+        const float send = odd ? mine_lo : mine_hi;
+        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
+        // even lane: row(e), channels (col, col+1) = (mine_lo, neighbour's acc[e]); odd: row(e+1), (col-1, col)
+        const int row = rbase + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2);
+        const unsigned v = odd ? cvt_pk_bf16(recv, mine_hi) : cvt_pk_bf16(mine_lo, recv);
+        *reinterpret_cast<unsigned*>(et + row * EPI_PITCH + (col & ~1) * 2) = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // one 32x32 block at a time: keeps the accumulator->VGPR copies short-lived
+    }
+  __syncthreads();
+
+  if (a.stats && tid < BN) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) {
+      s += red[(w * 2 + 0) * BN + tid];
+      ss += red[(w * 2 + 1) * BN + tid];
+    }
+    float* o = a.stats + (size_t)mt * 2 * a.Cout + n0 + tid;
+    o[0] = s;
+    o[a.Cout] = ss;
+  }
+
+  // ---- epilogue 3: full-line stores, 16 B (8 channels) per lane
+  constexpr int OCPR = BN / 8;
+  constexpr int OPASSES = (BM * OCPR + NTH - 1) / NTH;
+#pragma unroll
+  for (int i = 0; i < OPASSES; ++i) {
+    const int idx = tid + i * NTH;
+    const int row = idx / OCPR, cc = idx - row * OCPR;
+    const int m = m0 + row;
+    if (row < BM && m < a.M) {
+      size_t off;
+      if (a.os == 1) {                       // destination pixels are the GEMM pixels in order
+        off = (size_t)m * a.ldy + n0 + cc * 8;
+      } else {
+        const int pq = a.P * a.Q;
+        const int n = m / pq, rem = m - n * pq;
+        const int p = rem / a.Q, q = rem - p * a.Q;
+        off = ((size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0) * a.ldy + n0 + cc * 8;
+      }
+      uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
+      if (a.AS) {
+        const uint4 o = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + n0 + cc * 8);
+        const unsigned mb = a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)];
+        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+        const unsigned* po = reinterpret_cast<const unsigned*>(&o);
+        unsigned res[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = __uint_as_float(pv[k] << 16) + (((mb >> (2 * k)) & 1u) ? __uint_as_float(po[k] << 16) : 0.f);
+          const float hi = __uint_as_float(pv[k] & 0xffff0000u) +
+                           (((mb >> (2 * k + 1)) & 1u) ? __uint_as_float(po[k] & 0xffff0000u) : 0.f);
+          res[k] = pack_bf16x2(lo, hi);
+        }
+        v = make_uint4(res[0], res[1], res[2], res[3]);
+      }
+      if (a.accumulate) {
+        const uint4 o = *reinterpret_cast<const uint4*>(a.Y + off);
+        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+        const unsigned* po = reinterpret_cast<const unsigned*>(&o);
+        unsigned res[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = __uint_as_float(pv[k] << 16) + __uint_as_float(po[k] << 16);
+          const float hi = __uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(po[k] & 0xffff0000u);
+          res[k] = pack_bf16x2(lo, hi);
+        }
+        v = make_uint4(res[0], res[1], res[2], res[3]);
+      }
+      *reinterpret_cast<uint4*>(a.Y + off) = v;
+    }
+  }
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_gemm(ConvArgs a) {
   constexpr int NTH = WM * WN * 64;           // threads per workgroup (one wave per (wm, wn))
@@ -85,7 +211,6 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_g
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;   // bytes; pitch/4 % 32 == 16
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -231,118 +356,189 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 3 : 1)) k_conv_g
     __syncthreads();
   }
 
-  // ---- epilogue 1: BatchNorm batch statistics from the fp32 accumulators
-  // C/D layout of 32x32: col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel)
-  float* red = reinterpret_cast<float*>(smem + BM * EPI_PITCH);   // [WM][2][BN] floats, after the epilogue tile
-  if (a.stats) {
+  conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
+}
+
+// ---- LDS-DMA variant of the main loop -----------------------------------------------------------------------
+// Same tiles, same LDS image, same fragment reads and epilogue as k_conv_gemm, but the A/B tiles travel
+// global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write) into a ring of NST stages, with the
+// loads of the next NST-1 K-steps in flight ACROSS the per-step barrier: a counted s_waitcnt vmcnt retires only the
+// stage about to be read, and the barrier is a raw s_barrier (a __syncthreads() would drain the whole queue).
+// The register-staged loop exposes one global-load latency per K-step and per workgroup (load -> MFMA -> wait ->
+// ds_write -> barrier); here a workgroup's K-step costs its MFMAs plus one barrier.
+// An LDS-DMA instruction writes wave-uniform base + lane*16 B, i.e. 1 KB of consecutive tile rows: the XOR swizzle is
+// applied to the SOURCE chunk each lane fetches (slot s of row r holds logical chunk s ^ key(r)), the fragment reads
+// use the same involution.  Padding taps fetch from a zero page (the DMA cannot select a constant).
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[4];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  // gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; expcnt imm[6:4] and lgkmcnt imm[11:8] left at "no wait"
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NST>
+__global__ void __launch_bounds__(WM * WN * 64, 3) k_conv_dma(ConvArgs a) {
+  constexpr int NTH = WM * WN * 64;
+  constexpr int CPR = BK / 8;
+  constexpr int RPP = NTH / CPR;                       // rows per pass (one pass = one DMA instruction per wave)
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tiles must be whole passes");
+  constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP, LPS = A_PASSES + B_PASSES;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  int mt, nt;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    mt = lin / a.NT;
+    nt = lin - mt * a.NT;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int slot = tid % CPR, rrow = tid / CPR;
+  const int lchunk = swz<BK>(rrow, slot);              // logical chunk this lane fetches (same key for every pass)
+  int pix_base[A_PASSES], ph[A_PASSES], qw[A_PASSES];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[i][j][e];
-          s += v;
-          ss += v * v;
-        }
-      s += __shfl_xor(s, 32, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      if (lh == 0) {
-        const int c = wn * (BN / WN) + j * 32 + l31;
-        red[(wm * 2 + 0) * BN + c] = s;
-        red[(wm * 2 + 1) * BN + c] = ss;
-      }
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + rrow + i * RPP;
+    if (m < a.M) {
+      const int pq = a.P * a.Q;
+      const int n = m / pq, rem = m - n * pq;
+      const int p = rem / a.Q, q = rem - p * a.Q;
+      pix_base[i] = n * a.IH * a.IW;
+      ph[i] = p * a.ah + a.ch;
+      qw[i] = q * a.aw + a.cw;
+    } else {
+      pix_base[i] = -1; ph[i] = 0; qw[i] = 0;
     }
   }
+  const int cblocks = a.Cin / BK;
+  const int nk = a.R * a.S * cblocks;
+  const int dmask = (1 << a.log2d) - 1;
+  int woff[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) woff[i] = (n0 + rrow + i * RPP) * a.Kw + lchunk * 8;
+  // wave-uniform LDS byte offsets of this wave's 1 KB pieces inside a stage
+  const int piece_row0 = (wid * 64) / CPR;
 
-  // ---- epilogue 2: accumulators -> bf16 tile in LDS.  A lane holds ONE channel (column) of 16 pixel rows;
-  // neighbouring lanes swap one value (DPP quad_perm, no LDS traffic) so each lane owns a 2-channel pair,
-  // rounded by v_cvt_pk_bf16_f32 and written as one dword.
-  unsigned char* et = smem;
-  const bool odd = lane & 1;
+  int ld_r = 0, ld_s = 0, ld_cb = 0, wtap_off = 0;
+  int aoff[A_PASSES];
+  unsigned avalid = 0;
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+#define YV1_SET_TAP_D()                                                                                          \
+  {                                                                                                              \
+    avalid = 0;                                                                                                  \
+    wtap_off = ((a.wr0 + ld_r * a.wrs) * a.WS + (a.ws0 + ld_s * a.wss)) * a.Cin;                                 \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const int hn = ph[i] + ld_r * a.bh, wn_ = qw[i] + ld_s * a.bw;                                             \
+      const int ih = hn >> a.log2d, iw = wn_ >> a.log2d;                                                         \
+      const bool ok = pix_base[i] >= 0 && ((hn | wn_) & dmask) == 0 && hn >= 0 && wn_ >= 0 && ih < a.IH &&       \
+                      iw < a.IW;                                                                                 \
+      aoff[i] = ok ? (pix_base[i] + ih * a.IW + iw) * a.ldx + lchunk * 8 : 0;                                    \
+      avalid |= ok ? (1u << i) : 0u;                                                                             \
+    }                                                                                                            \
+  }
+#define YV1_ISSUE(STG_)                                                                                          \
+  {                                                                                                              \
+    unsigned char* sa_ = smem + (STG_) * STAGE;                                                                  \
+    unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
+    const int coff = ld_cb * BK;                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const bool ok = (avalid >> i) & 1u;                                                                        \
+      const bf16_t* src = ok ? a.X + (aoff[i] + coff) : zsrc;                                                    \
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sa_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
+      const bf16_t* src = a.W + (woff[i] + wtap_off + coff);                                                     \
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sb_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+    }                                                                                                            \
+    if (++ld_cb == cblocks) {                                                                                    \
+      ld_cb = 0;                                                                                                 \
+      if (++ld_s == a.S) { ld_s = 0; ++ld_r; }                                                                   \
+      YV1_SET_TAP_D();                                                                                           \
+    }                                                                                                            \
+  }
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = wn * (BN / WN) + j * 32 + l31;
-      const int rbase = wm * (BM / WM) + i * 32 + 4 * lh;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const float mine_lo = acc[i][j][e], mine_hi = acc[i][j][e + 1];
-        const float send = odd ? mine_lo : mine_hi;
-        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
-        // even lane: row(e), channels (col, col+1) = (mine_lo, neighbour's acc[e]); odd: row(e+1), (col-1, col)
-        const int row = rbase + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2);
-        const unsigned v = odd ? cvt_pk_bf16(recv, mine_hi) : cvt_pk_bf16(mine_lo, recv);
-        *reinterpret_cast<unsigned*>(et + row * EPI_PITCH + (col & ~1) * 2) = v;
-      }
-      __builtin_amdgcn_sched_barrier(0);   // one 32x32 block at a time: keeps the accumulator->VGPR copies short-lived
-    }
-  __syncthreads();
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (a.stats && tid < BN) {
-    float s = 0.f, ss = 0.f;
+  YV1_SET_TAP_D();
+  // prologue: K-steps 0 .. NST-2 in flight
 #pragma unroll
-    for (int w = 0; w < WM; ++w) {
-      s += red[(w * 2 + 0) * BN + tid];
-      ss += red[(w * 2 + 1) * BN + tid];
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nk) YV1_ISSUE(p);
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  int cur = 0, nxt = NST - 1;                          // stage read now / stage the next issue fills
+  for (int kt = 0; kt < nk; ++kt) {
+    // retire K-step kt: the younger in-flight steps (at most NST-2 of them) may stay outstanding
+    const int younger = min(nk - 1 - kt, NST - 2);
+    if (younger >= 2) wait_vmcnt<2 * LPS>();
+    else if (younger == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                      // everyone's pieces of step kt landed; everyone left stage nxt
+    if (kt + NST - 1 < nk) YV1_ISSUE(nxt);
+    const unsigned char* sa = smem + cur * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / WM) + i * 32 + l31;
+        fa[i] = *reinterpret_cast<const bf16x8*>(sa + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / WN) + j * 32 + l31;
+        fb[j] = *reinterpret_cast<const bf16x8*>(sb + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    float* o = a.stats + (size_t)mt * 2 * a.Cout + n0 + tid;
-    o[0] = s;
-    o[a.Cout] = ss;
+    cur = cur + 1 == NST ? 0 : cur + 1;
+    nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
+#undef YV1_SET_TAP_D
+#undef YV1_ISSUE
+  __syncthreads();                                     // all fragment reads done before the epilogue tile reuses LDS
+  conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
+}
 
-  // ---- epilogue 3: full-line stores, 16 B (8 channels) per lane
-  constexpr int OCPR = BN / 8;
-  constexpr int OPASSES = (BM * OCPR + NTH - 1) / NTH;
-#pragma unroll
-  for (int i = 0; i < OPASSES; ++i) {
-    const int idx = tid + i * NTH;
-    const int row = idx / OCPR, cc = idx - row * OCPR;
-    const int m = m0 + row;
-    if (row < BM && m < a.M) {
-      size_t off;
-      if (a.os == 1) {                       // destination pixels are the GEMM pixels in order
-        off = (size_t)m * a.ldy + n0 + cc * 8;
-      } else {
-        const int pq = a.P * a.Q;
-        const int n = m / pq, rem = m - n * pq;
-        const int p = rem / a.Q, q = rem - p * a.Q;
-        off = ((size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0) * a.ldy + n0 + cc * 8;
-      }
-      uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
-      if (a.AS) {
-        const uint4 o = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + n0 + cc * 8);
-        const unsigned mb = a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)];
-        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
-        const unsigned* po = reinterpret_cast<const unsigned*>(&o);
-        unsigned res[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float lo = __uint_as_float(pv[k] << 16) + (((mb >> (2 * k)) & 1u) ? __uint_as_float(po[k] << 16) : 0.f);
-          const float hi = __uint_as_float(pv[k] & 0xffff0000u) +
-                           (((mb >> (2 * k + 1)) & 1u) ? __uint_as_float(po[k] & 0xffff0000u) : 0.f);
-          res[k] = pack_bf16x2(lo, hi);
-        }
-        v = make_uint4(res[0], res[1], res[2], res[3]);
-      }
-      if (a.accumulate) {
-        const uint4 o = *reinterpret_cast<const uint4*>(a.Y + off);
-        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
-        const unsigned* po = reinterpret_cast<const unsigned*>(&o);
-        unsigned res[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float lo = __uint_as_float(pv[k] << 16) + __uint_as_float(po[k] << 16);
-          const float hi = __uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(po[k] & 0xffff0000u);
-          res[k] = pack_bf16x2(lo, hi);
-        }
-        v = make_uint4(res[0], res[1], res[2], res[3]);
-      }
-      *reinterpret_cast<uint4*>(a.Y + off) = v;
+template <int BM, int BN, int BK, int WM, int WN, int NST>
+int launch_dma(ConvArgs& a, hipStream_t stream) {
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
+  constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
+  constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
+  a.MT = (a.M + BM - 1) / BM;
+  a.NT = a.Cout / BN;
+  auto kern = k_conv_dma<BM, BN, BK, WM, WN, NST>;
+  if (LDS > 64 * 1024) {
+    static bool once = false;
+    if (!once) {
+      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+      once = true;
     }
   }
+  hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), LDS, stream, a);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
@@ -415,6 +611,38 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
   }
   int bn = 0;
   const int bm = choose_cfg(a.M, a.Cout, a.Cin, &bn);
+  {
+    // Default main loop: the LDS-DMA ring (k_conv_dma).  Measured per layer (tools/bench_conv.py, N=64): BK 32 with three
+    // stages (48 KB, 3 workgroups/CU, two K-steps in flight) wins on the bandwidth-bound feature maps; BK 64 with two
+    // stages (64 KB, 2 workgroups/CU) on the deep 3x3 / Cin >= 1024 layers; the 64x64 tiles of the 7x7 maps take BK 64
+    // with three stages.  YV1_CONV_DMA=0 selects the register-staged loop (k_conv_gemm), 2/3/4 force a stage count.
+    static int dma = -1;
+    if (dma < 0) { const char* e = getenv("YV1_CONV_DMA"); dma = e ? atoi(e) : 1; }
+    if (dma) {
+      const bool c64 = (a.Cin % 64) == 0;
+      bool d64 = c64 && ((a.R * a.S > 1 && a.M < 250000) || (a.Cin >= 1024 && a.M < 150000));
+      int nst = d64 ? 2 : 3;
+      if (bm == 64 && c64) { d64 = true; nst = 3; }
+      {
+        static int fbk = -1;
+        if (fbk < 0) { const char* e = getenv("YV1_CONV_BK"); fbk = e ? atoi(e) : 0; }
+        if (fbk == 32) { d64 = false; if (dma == 1) nst = 3; }
+        if (fbk == 64 && c64) { d64 = true; if (dma == 1) nst = (bm == 64) ? 3 : 2; }
+      }
+      if (dma >= 2) nst = dma > 4 ? 4 : dma;
+      if (d64 && nst > 3) nst = 3;
+#define YV1_DMA_CASE(BM_, BN_)                                                                                   \
+      if (bm == BM_ && bn == BN_) {                                                                              \
+        if (d64) return nst >= 3 ? launch_dma<BM_, BN_, 64, 2, 2, 3>(a, stream) : launch_dma<BM_, BN_, 64, 2, 2, 2>(a, stream); \
+        return nst >= 4 ? launch_dma<BM_, BN_, 32, 2, 2, 4>(a, stream)                                           \
+                        : (nst == 3 ? launch_dma<BM_, BN_, 32, 2, 2, 3>(a, stream) : launch_dma<BM_, BN_, 32, 2, 2, 2>(a, stream)); \
+      }
+      YV1_DMA_CASE(128, 128)
+      YV1_DMA_CASE(128, 64)
+      YV1_DMA_CASE(64, 64)
+#undef YV1_DMA_CASE
+    }
+  }
   if (bm == 256 && bn == 128 && k64) return launch<256, 128, 64, 4, 2>(a, stream);
   if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
   if (bm == 128 && bn == 64) return k64 ? launch<128, 64, 64, 2, 2>(a, stream) : launch<128, 64, 32, 2, 2>(a, stream);
