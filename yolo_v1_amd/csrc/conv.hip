@@ -378,7 +378,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NST>
-__global__ void __launch_bounds__(WM * WN * 64, 3) k_conv_dma(ConvArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) k_conv_dma(ConvArgs a) {
   constexpr int NTH = WM * WN * 64;
   constexpr int CPR = BK / 8;
   constexpr int RPP = NTH / CPR;                       // rows per pass (one pass = one DMA instruction per wave)
@@ -489,9 +489,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) k_conv_dma(ConvArgs a) {
     else if (younger == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                      // everyone's pieces of step kt landed; everyone left stage nxt
-    if (kt + NST - 1 < nk) YV1_ISSUE(nxt);
+    if (kt + NST - 1 < nk && !(a.dbg & 1)) YV1_ISSUE(nxt);
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + A_BYTES;
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 fa[TM], fb[TN];
@@ -631,12 +632,17 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
       }
       if (dma >= 2) nst = dma > 4 ? 4 : dma;
       if (d64 && nst > 3) nst = 3;
+      // one 256-wide column tile when it covers all of Cout: the gathered A rows are then fetched L2 -> LDS once
+      // instead of twice (these loops are bound by that bandwidth); 9 % on 256->256 3x3 @28, 3 % on 1024->256
+      if (dma == 1 && bm == 128 && bn == 128 && a.Cout == 256 && a.M <= 60000 && (a.R * a.S > 1 || a.Cin >= 1024))
+        return launch_dma<128, 256, 32, 2, 2, 3>(a, stream);
 #define YV1_DMA_CASE(BM_, BN_)                                                                                   \
       if (bm == BM_ && bn == BN_) {                                                                              \
         if (d64) return nst >= 3 ? launch_dma<BM_, BN_, 64, 2, 2, 3>(a, stream) : launch_dma<BM_, BN_, 64, 2, 2, 2>(a, stream); \
         return nst >= 4 ? launch_dma<BM_, BN_, 32, 2, 2, 4>(a, stream)                                           \
                         : (nst == 3 ? launch_dma<BM_, BN_, 32, 2, 2, 3>(a, stream) : launch_dma<BM_, BN_, 32, 2, 2, 2>(a, stream)); \
       }
+      YV1_DMA_CASE(128, 256)
       YV1_DMA_CASE(128, 128)
       YV1_DMA_CASE(128, 64)
       YV1_DMA_CASE(64, 64)
