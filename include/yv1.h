@@ -53,7 +53,7 @@ int yv1_decode_nms_batched(const float* pred, int N, int S, int B, int C, double
  *   t = bf16(acc * alpha[c] + beta[c]);  out = relu?(t + residual);  y_bf16 = bf16(out), y_fp8 = e4m3(clamp(bf16(out)))
  * x8 [N,IH,IW,*] e4m3 (pixel stride ldx bytes), w8 [Cout][k*k][Cin] e4m3 from yv1_prep_weights_fp8, residual /
  * y_bf16 bf16 with pixel strides ldr / ld16, y_fp8 e4m3 with pixel stride ld8; either output may be NULL.
- * Cin % 64 == 0, Cout % 32 == 0.  MFMA: v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales. */
+ * Cin % 64 == 0, Cout % 64 == 0 (pad the weight rows).  MFMA: v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales. */
 int yv1_conv2d_fwd_nhwc_fp8(const void* x8, const void* w8, const float* alpha, const float* beta, const void* residual,
                             int ldr, void* y_bf16, int ld16, void* y_fp8, int ld8, int N, int IH, int IW, int ldx, int Cin,
                             int Cout, int k, int stride, int pad, int relu, yv1_stream_t stream);

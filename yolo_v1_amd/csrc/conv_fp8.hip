@@ -11,8 +11,8 @@
 // e4m3 weights, each output channel pre-multiplied by a power of two q[n] so its largest weight lands just
 // below 448 (yv1_prep_weights_fp8) -- the dequantisation is folded into alpha.
 //
-// Same tiling as conv.hip (4 wave64s per workgroup, 32x32 accumulator blocks, register-staged double-buffered
-// LDS image with XOR-swizzled 16-B chunks, XCD-aware tile map) with 1-byte elements: a K-step is 64 or 128
+// Same tiling as conv.hip (4 wave64s per workgroup, 32x32 accumulator blocks, LDS-DMA ring of XOR-swizzled 16-B
+// chunks, XCD-aware tile map) with 1-byte elements: a K-step is 64 or 128
 // channels of one tap.  The MFMA takes 32 bytes per lane and operand: lane l supplies row (A) / column (B)
 // l&31 and the k-slab half l>>5 -- bytes [32h, 32h+32) of each 64-byte k-slab; A and B use the same assignment,
 // which is all the instruction needs (checked with exact integer data: tools/fp8_layout_probe.hip).  With both
@@ -62,19 +62,29 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
   return (unsigned)w;
 }
 
-template <int BM, int BN, int BKB, int WM, int WN>
+__device__ __attribute__((aligned(16))) unsigned g_zero_page8[4];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt8() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+// Main loop as in conv.hip's k_conv_dma: tiles travel global -> LDS by LDS-DMA into a ring of NST stages, the next
+// NST-1 K-steps stay in flight across the raw per-step barrier, swizzle on the source chunk, zero page for padding.
+template <int BM, int BN, int BKB, int WM, int WN, int NST>
 __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
   constexpr int NTH = WM * WN * 64;
   constexpr int CPR = BKB / 16;               // 16-B chunks (16 channels) per row
-  constexpr int ROWS_PER_PASS = NTH / CPR;
-  constexpr int A_PASSES = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-  constexpr int B_PASSES = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-  constexpr bool A_GUARD = (BM % ROWS_PER_PASS) != 0, B_GUARD = (BN % ROWS_PER_PASS) != 0;
+  constexpr int RPP = NTH / CPR;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tiles must be whole DMA passes");
+  constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP, LPS = A_PASSES + B_PASSES;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -89,12 +99,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
   }
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const int ccol = tid % CPR, rrow = tid / CPR;
+  const int slot = tid % CPR, rrow = tid / CPR;
+  const int lchunk = swz8<CPR>(rrow, slot);
   int pix_base[A_PASSES], ph[A_PASSES], qw[A_PASSES];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + rrow + i * ROWS_PER_PASS;
-    if (m < a.M && (!A_GUARD || rrow + i * ROWS_PER_PASS < BM)) {
+    const int m = m0 + rrow + i * RPP;
+    if (m < a.M) {
       const int pq = a.P * a.Q;
       const int n = m / pq, rem = m - n * pq;
       const int p = rem / a.Q, q = rem - p * a.Q;
@@ -110,14 +121,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
   const int nk = a.KS * a.KS * cblocks;
   int woff[B_PASSES];
 #pragma unroll
-  for (int i = 0; i < B_PASSES; ++i) {
-    const int row = rrow + i * ROWS_PER_PASS;
-    woff[i] = (n0 + ((!B_GUARD || row < BN) ? row : 0)) * Ktot + ccol * 16;
-  }
+  for (int i = 0; i < B_PASSES; ++i) woff[i] = (n0 + rrow + i * RPP) * Ktot + lchunk * 16;
+  const int piece_row0 = (wid * 64) / CPR;
 
   int ld_r = 0, ld_s = 0, ld_cb = 0, wtap_off = 0;
   int aoff[A_PASSES];
   unsigned avalid = 0;
+  const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(g_zero_page8);
 #define YV1_SET_TAP8()                                                                       \
   {                                                                                          \
     avalid = 0;                                                                              \
@@ -125,40 +135,28 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                   \
       const int ih = ph[i] + ld_r, iw = qw[i] + ld_s;                                        \
       const bool ok = pix_base[i] >= 0 && ih >= 0 && iw >= 0 && ih < a.IH && iw < a.IW;      \
-      aoff[i] = ok ? (pix_base[i] + ih * a.IW + iw) * a.ldx + ccol * 16 : 0;                 \
+      aoff[i] = ok ? (pix_base[i] + ih * a.IW + iw) * a.ldx + lchunk * 16 : 0;               \
       avalid |= ok ? (1u << i) : 0u;                                                         \
     }                                                                                        \
   }
-  u32x4 ra[A_PASSES], rb[B_PASSES];
-#define YV1_LOAD_TILES8()                                                                    \
+#define YV1_ISSUE8(STG_)                                                                     \
   {                                                                                          \
+    unsigned char* sa_ = smem + (STG_) * STAGE;                                              \
+    unsigned char* sb_ = sa_ + A_BYTES;                                                      \
     const int coff = ld_cb * BKB;                                                            \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                   \
       const bool ok = (avalid >> i) & 1u;                                                    \
-      u32x4 v = *reinterpret_cast<const u32x4*>(a.X + (aoff[i] + (ok ? coff : 0)));          \
-      const u32x4 z = {0u, 0u, 0u, 0u};                                                      \
-      ra[i] = ok ? v : z;                                                                    \
+      const unsigned char* src = ok ? a.X + (aoff[i] + coff) : zsrc;                         \
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sa_ + (piece_row0 + i * RPP) * BKB), 16, 0, 0); \
     }                                                                                        \
     _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                   \
-      rb[i] = *reinterpret_cast<const u32x4*>(a.W + (woff[i] + wtap_off + coff));            \
+      const unsigned char* src = a.W + (woff[i] + wtap_off + coff);                          \
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sb_ + (piece_row0 + i * RPP) * BKB), 16, 0, 0); \
     }                                                                                        \
     if (++ld_cb == cblocks) {                                                                \
       ld_cb = 0;                                                                             \
       if (++ld_s == a.KS) { ld_s = 0; ++ld_r; }                                              \
       YV1_SET_TAP8();                                                                        \
-    }                                                                                        \
-  }
-#define YV1_STORE_TILES8(BUF_)                                                               \
-  {                                                                                          \
-    unsigned char* sa_ = smem + (BUF_) * STAGE;                                              \
-    unsigned char* sb_ = sa_ + A_BYTES;                                                      \
-    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                   \
-      const int row = rrow + i * ROWS_PER_PASS;                                              \
-      if (!A_GUARD || row < BM) *reinterpret_cast<u32x4*>(sa_ + row * BKB + swz8<CPR>(row, ccol) * 16) = ra[i]; \
-    }                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                   \
-      const int row = rrow + i * ROWS_PER_PASS;                                              \
-      if (!B_GUARD || row < BN) *reinterpret_cast<u32x4*>(sb_ + row * BKB + swz8<CPR>(row, ccol) * 16) = rb[i]; \
     }                                                                                        \
   }
 
@@ -171,15 +169,18 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   YV1_SET_TAP8();
-  YV1_LOAD_TILES8();
-  YV1_STORE_TILES8(0);
-  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nk) YV1_ISSUE8(p);
 
   const int l31 = lane & 31, lh = lane >> 5;
+  int cur = 0, nxt = NST - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool do_ld = kt + 1 < nk;
-    if (do_ld) YV1_LOAD_TILES8();
+    const int younger = min(nk - 1 - kt, NST - 2);
+    if (younger >= 1) wait_vmcnt8<LPS>();
+    else wait_vmcnt8<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < nk) YV1_ISSUE8(nxt);
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
@@ -207,9 +208,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
                                                                       0x7f7f7f7f);
     }
-    if (do_ld) YV1_STORE_TILES8(cur ^ 1);
-    __syncthreads();
+    cur = cur + 1 == NST ? 0 : cur + 1;
+    nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
+  __syncthreads();
 
   // ---- epilogue 1: t = bf16(acc * alpha + beta), staged through LDS (layout and DPP pairing as in conv.hip)
   unsigned char* et = smem;
@@ -284,43 +286,41 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
     }
   }
 #undef YV1_SET_TAP8
-#undef YV1_LOAD_TILES8
-#undef YV1_STORE_TILES8
+#undef YV1_ISSUE8
 }
 
-template <int BM, int BN, int BKB, int WM, int WN>
+template <int BM, int BN, int BKB, int WM, int WN, int NST>
 int launch8(Conv8Args& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BKB;
   constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
   constexpr int EPI = BM * EPI_PITCH;
+  constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
-  const int nk = a.KS * a.KS * (a.Cin / BKB);
-  const size_t stage_bytes = (size_t)(nk > 1 ? 2 : 1) * STAGE;
-  const size_t lds = stage_bytes > (size_t)EPI ? stage_bytes : (size_t)EPI;
-  auto kern = k_conv_fp8<BM, BN, BKB, WM, WN>;
-  constexpr size_t MAXLDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-  if (MAXLDS > 64 * 1024) {
+  auto kern = k_conv_fp8<BM, BN, BKB, WM, WN, NST>;
+  if (LDS > 64 * 1024) {
     static bool once = false;
     if (!once) {
-      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAXLDS));
+      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
       once = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), LDS, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
 
+// Stage counts: 64-byte K-steps take three stages (3 x 16 KB for the 128x128 tile), 128-byte K-steps two (2 x 32 KB).
 template <int BKB>
 int dispatch8(Conv8Args& a, hipStream_t stream) {
+  constexpr int NST = BKB == 64 ? 3 : 2;
   const long long tiles128 = (long long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-  if (a.Cout % 128 == 0 && tiles128 >= 192) return launch8<128, 128, BKB, 2, 2>(a, stream);
+  if (a.Cout % 128 == 0 && tiles128 >= 192) return launch8<128, 128, BKB, 2, 2, NST>(a, stream);
   if (a.Cout % 64 == 0) {
     const long long tiles = (long long)((a.M + 127) / 128) * (a.Cout / 64);
-    return tiles >= 512 ? launch8<128, 64, BKB, 2, 2>(a, stream) : launch8<64, 64, BKB, 2, 2>(a, stream);
+    return tiles >= 512 ? launch8<128, 64, BKB, 2, 2, NST>(a, stream) : launch8<64, 64, BKB, 2, 2, 3>(a, stream);
   }
-  return launch8<128, 32, BKB, 4, 1>(a, stream);
+  return YV1_ERR_UNSUPPORTED;
 }
 
 // bf16 NHWC -> e4m3 NHWC, 8 channels per thread
@@ -400,7 +400,7 @@ extern "C" int yv1_conv2d_fwd_nhwc_fp8(const void* x8, const void* w8, const flo
                                        int IH, int IW, int ldx, int Cin, int Cout, int k, int stride, int pad, int relu,
                                        yv1_stream_t stream) {
   if (!x8 || !w8 || !alpha || !beta || (!y_bf16 && !y_fp8) || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
-  if (Cin % 64 || Cout % 32 || ldx % 16) return YV1_ERR_UNSUPPORTED;
+  if (Cin % 64 || Cout % 64 || ldx % 16) return YV1_ERR_UNSUPPORTED;
   if ((y_bf16 && ld16 % 8) || (y_fp8 && ld8 % 8) || (residual && ldr % 8)) return YV1_ERR_UNSUPPORTED;
   Conv8Args a;
   a.X = (const unsigned char*)x8; a.W = (const unsigned char*)w8; a.alpha = alpha; a.beta = beta;

@@ -50,7 +50,7 @@ class Fp8Conv:
         dev = w.device
         self.k, self.stride, self.pad = conv.kernel_size, conv.stride, conv.padding
         self.O, self.I = w.shape[0], w.shape[1]
-        self.Opad = (self.O + 31) // 32 * 32
+        self.Opad = (self.O + 63) // 64 * 64
         if self.I % 64:
             raise ValueError("fp8 convolution needs Cin % 64 == 0 (got %d)" % self.I)
         s = stream_ptr(dev)
