@@ -649,7 +649,6 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
 #undef YV1_DMA_CASE
     }
   }
-  if (bm == 256 && bn == 128 && k64) return launch<256, 128, 64, 4, 2>(a, stream);
   if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
   if (bm == 128 && bn == 64) return k64 ? launch<128, 64, 64, 2, 2>(a, stream) : launch<128, 64, 32, 2, 2>(a, stream);
   if (bm == 64 && bn == 64) return k64 ? launch<64, 64, 64, 2, 2>(a, stream) : launch<64, 64, 32, 2, 2>(a, stream);
