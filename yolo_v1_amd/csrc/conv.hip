@@ -642,6 +642,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         return nst >= 4 ? launch_dma<BM_, BN_, 32, 2, 2, 4>(a, stream)                                           \
                         : (nst == 3 ? launch_dma<BM_, BN_, 32, 2, 2, 3>(a, stream) : launch_dma<BM_, BN_, 32, 2, 2, 2>(a, stream)); \
       }
+      if (bm == 128 && bn == 32 && c64) return launch_dma<128, 32, 64, 4, 1, 3>(a, stream);   // DenseNet growth convs
       YV1_DMA_CASE(128, 256)
       YV1_DMA_CASE(128, 128)
       YV1_DMA_CASE(128, 64)
