@@ -85,24 +85,28 @@ __global__ void __launch_bounds__(1024) k_stats_merge(const float* __restrict__ 
 // 1024 threads: tx = channel (64 per workgroup), ty = row lane (16): every row lane sums rows ty, ty+4, ... with 4 independent loads in flight, the 4 partial sums are combined
 // through LDS in a fixed order, then lane 0 does the per-channel math.  One launch replaces the former
 // reduce_rows + finalize pair.
+template <int CPB>
 __global__ void __launch_bounds__(1024) k_bn_finalize(const float* __restrict__ part, int rows, int C, int ldp, float count,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float momentum, float* running_mean, float* running_var,
                                                      float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                      float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  __shared__ float red[2][16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
+  // CPB channels per workgroup x RL = 1024/CPB row lanes.  CPB 64 reads full 256-B lines; CPB 16 spreads a narrow
+  // BatchNorm (C <= 1024) over 4x the workgroups -- these launches are latency-bound, not bandwidth-bound.
+  constexpr int RL = 1024 / CPB;
+  __shared__ float red[2][RL][CPB];
+  const int tx = threadIdx.x % CPB, ty = threadIdx.x / CPB;
+  const int c = blockIdx.x * CPB + tx;
   float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
   if (c < C) {
     int r = ty;
-    for (; r + 16 < rows; r += 32) {
+    for (; r + RL < rows; r += 2 * RL) {
       s0 += part[(size_t)r * 2 * ldp + c];
       q0 += part[(size_t)r * 2 * ldp + ldp + c];
-      s1 += part[(size_t)(r + 16) * 2 * ldp + c];
-      q1 += part[(size_t)(r + 16) * 2 * ldp + ldp + c];
+      s1 += part[(size_t)(r + RL) * 2 * ldp + c];
+      q1 += part[(size_t)(r + RL) * 2 * ldp + ldp + c];
     }
-    for (; r < rows; r += 16) {
+    for (; r < rows; r += RL) {
       s0 += part[(size_t)r * 2 * ldp + c];
       q0 += part[(size_t)r * 2 * ldp + ldp + c];
     }
@@ -112,8 +116,8 @@ __global__ void __launch_bounds__(1024) k_bn_finalize(const float* __restrict__ 
   __syncthreads();
   if (ty != 0 || c >= C) return;
   float s = 0.f, ss = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) { s += red[0][j][tx]; ss += red[1][j][tx]; }
+#pragma unroll 16
+  for (int j = 0; j < RL; ++j) { s += red[0][j][tx]; ss += red[1][j][tx]; }
   const float mean = s / count;
   float var = ss / count - mean * mean;
   var = var < 0.f ? 0.f : var;
@@ -322,24 +326,26 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
 
 // dgamma = sum dyh*xhat, dbeta = sum dyh;  dy = k1*dyh - k2 - xhat*k3 with
 // k1 = gamma*invstd, k2 = k1*dbeta/n, k3 = k1*dgamma/n
+template <int CPB>
 __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restrict__ part, int rows, int C, float count,
                                                          const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                          float* __restrict__ k1, float* __restrict__ k2,
                                                          float* __restrict__ k3) {
-  __shared__ float red[2][16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
+  constexpr int RL = 1024 / CPB;                 // see k_bn_finalize
+  __shared__ float red[2][RL][CPB];
+  const int tx = threadIdx.x % CPB, ty = threadIdx.x / CPB;
+  const int c = blockIdx.x * CPB + tx;
   float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
   if (c < C) {
     int r = ty;
-    for (; r + 16 < rows; r += 32) {
+    for (; r + RL < rows; r += 2 * RL) {
       s0 += part[(size_t)r * 2 * C + c];
       q0 += part[(size_t)r * 2 * C + C + c];
-      s1 += part[(size_t)(r + 16) * 2 * C + c];
-      q1 += part[(size_t)(r + 16) * 2 * C + C + c];
+      s1 += part[(size_t)(r + RL) * 2 * C + c];
+      q1 += part[(size_t)(r + RL) * 2 * C + C + c];
     }
-    for (; r < rows; r += 16) {
+    for (; r < rows; r += RL) {
       s0 += part[(size_t)r * 2 * C + c];
       q0 += part[(size_t)r * 2 * C + C + c];
     }
@@ -349,8 +355,8 @@ __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restric
   __syncthreads();
   if (ty != 0 || c >= C) return;
   float s = 0.f, sx = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) { s += red[0][j][tx]; sx += red[1][j][tx]; }
+#pragma unroll 16
+  for (int j = 0; j < RL; ++j) { s += red[0][j][tx]; sx += red[1][j][tx]; }
   if (dgamma) dgamma[c] = sx;
   if (dbeta) dbeta[c] = s;
   const float g = gamma ? gamma[c] : 1.f;
@@ -706,11 +712,30 @@ extern "C" int yv1_stats_merge(const float* partials, int rows, int Cseg, float*
   return YV1_OK;
 }
 
+// channels per workgroup of the finalize kernels (tuning: YV1_BN_FIN_CPB=8|16|64, YV1_BN_FIN_MAXC=<widest C split>)
+static int finalize_cpb(int C) {
+  static int cpb = 0, maxc = 0;
+  if (!cpb) {
+    const char* e = getenv("YV1_BN_FIN_CPB"); cpb = e ? atoi(e) : 16;
+    if (cpb != 8 && cpb != 16 && cpb != 64) cpb = 16;
+    const char* m = getenv("YV1_BN_FIN_MAXC"); maxc = m ? atoi(m) : 4096;
+  }
+  return C <= maxc ? cpb : 64;
+}
+
 extern "C" int yv1_bn_finalize(const float* partials, int rows, int C, int ld_partials, float count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                float* mean, float* invstd, float* scale, float* shift, hipStream_t stream) {
   if (!partials || rows <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return YV1_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, rows, C, ld_partials, count, gamma,
+  const int cpb = finalize_cpb(C);
+  if (cpb == 8)
+    hipLaunchKernelGGL(k_bn_finalize<8>, dim3((C + 7) / 8), dim3(1024), 0, stream, partials, rows, C, ld_partials, count, gamma,
+                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  else if (cpb == 16)
+    hipLaunchKernelGGL(k_bn_finalize<16>, dim3((C + 15) / 16), dim3(1024), 0, stream, partials, rows, C, ld_partials, count, gamma,
+                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  else
+    hipLaunchKernelGGL(k_bn_finalize<64>, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, rows, C, ld_partials, count, gamma,
                      beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
@@ -805,8 +830,16 @@ extern "C" int yv1_bn_bwd_finalize(const float* partials, int rows, int C, float
                                    const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
                                    hipStream_t stream) {
   if (!partials || rows <= 0 || C <= 0 || !invstd || !k1 || !k2 || !k3) return YV1_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, rows, C, count, gamma, invstd,
-                     dgamma, dbeta, k1, k2, k3);
+  const int cpb = finalize_cpb(C);
+  if (cpb == 8)
+    hipLaunchKernelGGL(k_bn_bwd_finalize<8>, dim3((C + 7) / 8), dim3(1024), 0, stream, partials, rows, C, count, gamma,
+                       invstd, dgamma, dbeta, k1, k2, k3);
+  else if (cpb == 16)
+    hipLaunchKernelGGL(k_bn_bwd_finalize<16>, dim3((C + 15) / 16), dim3(1024), 0, stream, partials, rows, C, count, gamma,
+                       invstd, dgamma, dbeta, k1, k2, k3);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_finalize<64>, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, rows, C, count, gamma,
+                       invstd, dgamma, dbeta, k1, k2, k3);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
