@@ -175,22 +175,28 @@ class ResNet(HipBackbone):
                 # identity shortcut: its contribution to g_in (g where the block output was positive) is added in
                 # the epilogue of conv1's dgrad below
                 grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
-            grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side)
+            # the data gradient (critical path) is enqueued BEFORE the weight gradient that reads the same dy: launched
+            # the other way round, the side stream's wgrad workgroups fill the CUs first and the dgrad waits behind
+            # them (50 us per layer in the trace); this way the wgrad runs beside the bandwidth-bound BN kernels
+            mk = side.mark()
             dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
             ops.conv_dgrad(dy3, w3, dz2)
+            grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side, after=mk)
             dy2 = ops.new_act(N, y2.H, y2.W, y2.C, dev)
             grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
-            grads[blk.conv2.weight] = ops.conv_wgrad(z1, dy2, w2, side)
+            mk = side.mark()
             dz1 = ops.new_act(N, z1.H, z1.W, z1.C, dev)
             ops.conv_dgrad(dy2, w2, dz1)
+            grads[blk.conv2.weight] = ops.conv_wgrad(z1, dy2, w2, side, after=mk)
             dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
             grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
-            grads[blk.conv1.weight] = ops.conv_wgrad(x, dy1, w1, side)
+            mk = side.mark()
             if yd is not None:
                 ops.conv_dgrad(dy1, w1, g_in, accumulate=False)
                 ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate
             else:
                 ops.conv_dgrad_add_masked(dy1, w1, g_in, g, omask)
+            grads[blk.conv1.weight] = ops.conv_wgrad(x, dy1, w1, side, after=mk)
             self._emit(grads, list(blk.parameters()))
             g = g_in
             if self._phase_boundary is not None and blk is boundary_blk:

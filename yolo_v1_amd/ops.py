@@ -202,11 +202,25 @@ class SideStream:
         self.side = _side_stream_for(device) if enabled else None
         self.keep = []
 
-    def run(self, fn, *keep_alive):
-        """fn() launches kernels; they are ordered after everything issued on the main stream so far."""
+    def mark(self):
+        """Event at the current end of the main stream: ``run(..., after=mark)`` orders side work after THIS point, so
+        main-stream kernels launched between mark() and run() (the data gradient -- the critical path) are enqueued
+        ahead of the side work without the side work having to wait for them."""
+        if self.side is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        return ev
+
+    def run(self, fn, *keep_alive, after=None):
+        """fn() launches kernels; they are ordered after ``after`` (a mark()) or, without it, after everything issued
+        on the main stream so far."""
         if self.side is None:
             return fn()
-        self.side.wait_stream(self.main)
+        if after is not None:
+            self.side.wait_event(after)
+        else:
+            self.side.wait_stream(self.main)
         with torch.cuda.stream(self.side):
             out = fn()
         self.keep.extend(keep_alive)
@@ -228,9 +242,9 @@ def _side_stream_for(device):
     return _SIDE_STREAMS[key]
 
 
-def conv_wgrad(x, dy, w, side=None):
+def conv_wgrad(x, dy, w, side=None, after=None):
     """Returns the fp32 gradient as an OIHW view whose storage is [O][kh][kw][I] (channels_last).
-    With ``side`` (a SideStream) the kernels run on the side stream."""
+    With ``side`` (a SideStream) the kernels run on the side stream, ordered after ``after`` (SideStream.mark())."""
     dev = x.t.device
     L = lib()
     taps = w.k * w.k
@@ -244,7 +258,7 @@ def conv_wgrad(x, dy, w, side=None):
     if side is None:
         launch()
     else:
-        side.run(launch, x.t, dy.t, ws, g)
+        side.run(launch, x.t, dy.t, ws, g, after=after)
     return g[:w.O].view(w.O, w.k, w.k, w.Ipad).permute(0, 3, 1, 2)
 
 
