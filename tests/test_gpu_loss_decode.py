@@ -264,3 +264,44 @@ def test_device_prefetcher_feeds_encoded_batches():
     loader2 = torch.utils.data.DataLoader(ds_enc, batch_size=5, shuffle=False, num_workers=0)
     got = [t.cpu() for _, t in DevicePrefetcher(loader2, dev, S=7)]
     assert torch.equal(torch.cat(got), torch.stack([ds_enc[i][1] for i in range(10)]))
+
+
+@pytest.mark.parametrize("S,B,C", [(7, 1, 20), (7, 3, 5), (14, 2, 1), (5, 4, 11)])
+def test_loss_decoder_encoder_other_B_and_C(dev, S, B, C):
+    """The reference layers take B (boxes per cell) and the class count as constructor arguments (v1Loss.py:10,
+    utils/utils.py:94, YOLODataLoader.py:13); everything above runs B=2, C=20.  Same parity bars for other values:
+    loss/grad 1e-5 vs the oracle, encoder bit-exact, decoder boxes/classes/keep indices bit-exact."""
+    from oracle import boxes as obx, loss as ol
+    from yolo_v1_amd.utils.YOLODataLoader import collate_raw, encode_targets_device
+    from yolo_v1_amd.utils.utils import decode_batch
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    g = torch.Generator().manual_seed(S * 100 + B * 10 + C)
+    N, D = 6, B * 5 + C
+    samples = []
+    for i in range(N):
+        k = [0, 1, 2, 3, 5, 9][i]
+        boxes = torch.cat([torch.rand(k, 2, generator=g).clamp_(1e-3, 1.0), torch.rand(k, 2, generator=g) * 0.8 + 0.05], 1)
+        samples.append((torch.zeros(1), boxes, torch.randint(0, C, (k,), generator=g)))
+    _, bx, lb, cnt = collate_raw(samples)
+    target = encode_targets_device(bx.to(dev), lb.to(dev), cnt.to(dev), S, B, C)
+    want_t = np.stack([obx.encode_target(s[1].numpy(), s[2].numpy(), S, B, C) for s in samples])
+    np.testing.assert_array_equal(target.cpu().numpy(), want_t)
+    pred = torch.rand(N, S, S, D, generator=g) * 0.96 + 0.02
+    ref_loss, ref_comps, ref_grad = ol.yolo_loss_and_grad(pred, torch.tensor(want_t), S, B, C, 5.0, 0.5, N)
+    p = pred.to(dev).requires_grad_(True)
+    layer = YOLOLossV1(N, S, B, C, _quiet=True)
+    loss = layer(p, target)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(layer.last_components.cpu().numpy(), ref_comps, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), ref_grad, rtol=1e-5, atol=1e-6)
+    boxes, cls, probs, keep, counts, ncand = decode_batch(pred.to(dev), grid_num=S, B=B, thresh=0.25, nms_th=0.45)
+    for n in range(N):
+        wb, wc, wp, wk = obx.decoder(pred[n].numpy(), grid_num=S, B=B, thresh=0.25, nms_th=0.45)
+        k = int(counts[n])
+        assert k == len(wk)
+        if int(ncand[n]) > 0:
+            np.testing.assert_array_equal(keep[n, :k].cpu().numpy(), wk)
+        np.testing.assert_array_equal(cls[n, :k].cpu().numpy(), wc)
+        np.testing.assert_allclose(boxes[n, :k].cpu().numpy(), wb, rtol=0, atol=1.2e-7)
+        np.testing.assert_allclose(probs[n, :k].cpu().numpy(), wp, rtol=0, atol=1e-7)
