@@ -339,3 +339,37 @@ def test_batched_eval_loop_matches_per_image_oracle_pipeline():
                 preds[VOC_CLASSES[int(cl[j])]].append([fname.split('.')[0], float(pr[j])] + [int(v * 128) for v in bx[j]])
     want, _ = ov.voc_eval(preds, target, VOC_CLASSES)
     assert abs(got - want) < 1e-12, (got, want)
+
+
+def test_non_square_images_forward_backward_vs_oracle():
+    """H != W (the reference only ever feeds 448x448, but nothing in its modules assumes a square): rows and columns
+    must not be mixed up anywhere in the NHWC kernels (tap offsets, pooling windows, parity-decomposed dgrad, halo of
+    the multi-tap wgrad).  Training-mode forward + backward of the S=14 network on 128x320 images."""
+    from oracle import backbones as ob
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    S, N, H, W = 14, 4, 128, 320
+    P = ob.init_params(ob.resnet50_param_shapes(S), "resnet", seed=5)
+    for k in P:
+        if k.endswith("bn3.weight"):
+            P[k] = P[k] * 0.2
+    net = resnet50(S=S)
+    net.load_state_dict(P, strict=True)
+    net = net.to(DEV).train()
+    x = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(2))
+    for k, v in P.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    ref = ob.resnet50_forward(x, P, S, training=True, q=ob.bf16_ste)
+    gup = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3)) * 1e-2
+    ref.backward(gup)
+    pred = net(x.to(DEV))
+    assert tuple(pred.shape) == (N, H // 32, W // 32, 30)
+    d = (pred.detach().cpu() - ref.detach()).abs()
+    assert d.max().item() <= 5e-2 and d.mean().item() <= 1e-2, (d.max().item(), d.mean().item())
+    pred.backward(gup.to(DEV))
+    sd = dict(net.named_parameters())
+    for k in ("conv1.weight", "layer1.0.conv2.weight", "layer2.0.conv2.weight", "layer2.0.downsample.0.weight",
+              "layer3.2.conv2.weight", "layer4.1.conv1.weight", "layer6.weight", "bn1.weight"):
+        a, b = sd[k].grad.detach().cpu(), P[k].grad
+        assert _cos(a, b) >= 0.90, (k, _cos(a, b))
+        assert 0.85 <= float(a.norm() / b.norm()) <= 1.15, (k, float(a.norm() / b.norm()))
