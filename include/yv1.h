@@ -91,6 +91,14 @@ int yv1_conv2d_stats_rows(int M, int Cout, int Cin);
 int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy, float* stats,
                              yv1_stream_t stream);
 int yv1_pack_input_nhwc4(const float* x_nchw, void* y, int N, int H, int W, yv1_stream_t stream);
+/* inference forms (network in eval() mode, OriginResNet.py:87-107,:174-176): conv + folded BatchNorm (scale/shift per
+ * output channel, yv1_bn_eval_coeffs) + bf16 residual + ReLU in one launch:
+ *   t = bf16(acc * scale[c] + shift[c]);  y = bf16(relu?(t + residual));  without residual the ReLU precedes the rounding */
+int yv1_conv2d_fwd_bn_act_nhwc_bf16(const void* x, const void* w, void* y, int N, int IH, int IW, int ldx, int Cin, int Cout,
+                                    int ldy, int k, int stride, int pad, const float* scale, const float* shift,
+                                    const void* residual, int ldres, int relu, yv1_stream_t stream);
+int yv1_conv2d_stem_fwd_bn_act_bf16(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy,
+                                    const float* scale, const float* shift, int relu, yv1_stream_t stream);
 /* dx (+)= conv_transpose(dy, w); wt bf16 [Cin][k*k][Cout]; stride 1 or 2.  1x1 strided: only the sampled
  * pixels of dx are written (accumulate into a dx the main path already wrote). */
 int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin, int Cout,

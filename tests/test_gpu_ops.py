@@ -319,3 +319,36 @@ def test_conv_dgrad_add_masked_equals_two_step_path(N, H, Wd, Cin, Cout):
     assert torch.equal(dx_new.t, dres.t)
     ref = F.conv_transpose2d(dy[:, :Cout], w) + torch.where(m, gout, torch.zeros_like(gout))
     close(to_nchw(dx_new), ref, rtol=2e-2, scale_atol=2e-2)
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,k,stride,use_res,relu", [
+    (2, 16, 16, 64, 64, 3, 1, False, True), (2, 16, 16, 64, 256, 1, 1, True, True), (3, 14, 14, 256, 512, 1, 2, False, False),
+    (9, 28, 28, 256, 256, 3, 1, True, True), (2, 14, 10, 1024, 256, 1, 1, False, True), (2, 16, 16, 128, 128, 3, 2, False, True)])
+def test_conv_fwd_bn_act_inference_epilogue(N, H, Wd, Cin, Cout, k, stride, use_res, relu):
+    """conv + folded eval-mode BatchNorm + residual + ReLU in one launch vs fp32 math on the same bf16 operands.
+    Definition: t = bf16(acc*scale + shift); y = bf16(relu(t + residual)) -- tolerance one bf16 rounding of t plus one of y."""
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(N + Cin + Cout + k)
+    pad = k // 2
+    x = bf(torch.randn(N, Cin, H, Wd, generator=g))
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+    bn = torch.nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    bn = bn.to(DEV).eval()
+    wm = W(w, k, stride, pad)
+    ref = F.conv2d(x, w, stride=stride, padding=pad)
+    OH, OW = ref.shape[2:]
+    ref = F.batch_norm(ref, bn.running_mean.cpu(), bn.running_var.cpu(), bn.weight.detach().cpu(), bn.bias.detach().cpu(), False, 0.1, 1e-5)
+    res = bf(torch.randn(N, Cout, OH, OW, generator=g)) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    ya = ops.new_act(N, OH, OW, Cout, DEV)
+    ops.conv_fwd_bn_act(nhwc_act(x), wm.cw, ya, ops.bn_eval_state(bn), relu=relu, residual=nhwc_act(res) if use_res else None)
+    torch.cuda.synchronize()
+    close(to_nchw(ya), ref, rtol=1.5e-2, scale_atol=1.5e-2)

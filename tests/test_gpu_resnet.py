@@ -373,3 +373,33 @@ def test_non_square_images_forward_backward_vs_oracle():
         a, b = sd[k].grad.detach().cpu(), P[k].grad
         assert _cos(a, b) >= 0.90, (k, _cos(a, b))
         assert 0.85 <= float(a.norm() / b.norm()) <= 1.15, (k, float(a.norm() / b.norm()))
+
+
+def test_fused_eval_forward_matches_unfused_and_oracle():
+    """eval(): one launch per convolution (BatchNorm folded into the epilogue) against the separate conv / BN-apply
+    launches of the same network and against the fp32 oracle."""
+    from oracle import backbones as ob
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    S = 7
+    P = ob.init_params(ob.resnet50_param_shapes(S), "resnet", seed=4)
+    for k in P:
+        if k.endswith("running_var"):
+            P[k] = P[k] * 1.3 + 0.2
+        if k.endswith("running_mean"):
+            P[k] = P[k] - 0.03
+        if k.endswith("bn3.weight"):
+            P[k] = P[k] * 0.3
+    net = resnet50(S=S)
+    net.load_state_dict(P)
+    net = net.to(DEV).eval()
+    x = torch.randn(3, 3, 128, 192, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        assert net.fused_eval
+        a = net(x.to(DEV)).cpu()
+        net.fused_eval = False
+        b = net(x.to(DEV)).cpu()
+        net.fused_eval = True
+        ref = ob.resnet50_forward(x, P, S, training=False)
+    assert (a - b).abs().max().item() <= 2e-2 and (a - b).abs().mean().item() <= 3e-3
+    assert (a - ref).abs().max().item() <= 2e-2 and (a - ref).abs().mean().item() <= 3e-3
+    assert (a - ref).abs().mean().item() <= (b - ref).abs().mean().item() * 1.2 + 1e-4     # one rounding fewer per layer

@@ -41,6 +41,9 @@ SIGNATURES = {
     # conv.hip
     "yv1_conv2d_fwd_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "yv1_conv2d_stem_fwd_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "yv1_conv2d_fwd_bn_act_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
+                                              c_i, c_i, c_p]),
+    "yv1_conv2d_stem_fwd_bn_act_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "yv1_conv2d_dgrad_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "yv1_conv2d_dgrad_add_masked_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i,
                                                     c_p]),

@@ -78,12 +78,47 @@ class ResNet(HipBackbone):
             for blk in getattr(self, name):
                 yield blk
 
+    def _run_forward_eval(self, images):
+        """eval() mode: BatchNorm uses its running statistics, so it folds into per-channel scale/shift and rides in
+        the convolution epilogue together with the residual add and the ReLU -- one launch per convolution, no
+        stand-alone BatchNorm pass, no raw conv outputs kept (there is no backward in this mode)."""
+        dev = images.device
+        N, _, H, W = images.shape
+        w0 = self.cw(self.conv1, stem=True)
+        xp = ops.pack_input(images)
+        z0 = ops.new_act(N, H // 2, W // 2, 64, dev)
+        ops.stem_fwd_bn_act(xp, w0, z0, H, W, ops.bn_eval_state(self.bn1), relu=True)
+        x = ops.new_act(N, H // 4, W // 4, 64, dev)
+        ops.maxpool_fwd(z0, x)
+        for blk in self._blocks():
+            w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
+            planes = blk.conv1.out_channels
+            z1 = ops.new_act(N, x.H, x.W, planes, dev)
+            ops.conv_fwd_bn_act(x, w1, z1, ops.bn_eval_state(blk.bn1))
+            h2, w2_ = ops.conv_out_hw(x.H, x.W, 3, blk.stride, 1)
+            z2 = ops.new_act(N, h2, w2_, planes, dev)
+            ops.conv_fwd_bn_act(z1, w2, z2, ops.bn_eval_state(blk.bn2))
+            if blk.downsample is not None:
+                res = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
+                ops.conv_fwd_bn_act(x, self.cw(blk.downsample[0]), res, ops.bn_eval_state(blk.downsample[1]), relu=False)
+            else:
+                res = x
+            out = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
+            ops.conv_fwd_bn_act(z2, w3, out, ops.bn_eval_state(blk.bn3), relu=True, residual=res)
+            x = out
+        wh = self.cw(self.layer6)
+        yh = ops.new_act(N, x.H, x.W, wh.Opad, dev)
+        ops.conv_fwd(x, wh, yh, False)
+        return ops.head_fwd(yh, ops.bn_eval_state(self.bn_end), self.out_channels)
+
     def _run_forward(self, images, train, save):
         dev = images.device
         N, _, H, W = images.shape
         if H % 64 or W % 64:
             raise _lib.Yv1Error("input height/width must be multiples of 64, got %dx%d" % (H, W))
         self.refresh_all_weights()
+        if not train and self.fused_eval:
+            return self._run_forward_eval(images), None
         bns = []
 
         def norm(stats, count, bn, C=None):

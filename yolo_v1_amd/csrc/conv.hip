@@ -56,6 +56,10 @@ struct ConvArgs {
   const bf16_t* AS;             // optional: out += AM-bit ? AS[m][n] : 0 (shortcut gradient through a ReLU, see
   const unsigned char* AM;      //           yv1_conv2d_dgrad_add_masked_nhwc_bf16); AM is [M][ldam] bytes, bit k of
   int ldas, ldam;               //           byte j = channel 8j+k
+  const float* escale;          // optional inference epilogue: t = bf16(acc * escale[n] + eshift[n]) (folded eval-mode
+  const float* eshift;          //   BatchNorm), out = t + ERES (bf16 residual), ReLU if erelu
+  const bf16_t* ERES;
+  int ldres, erelu;
   int M;
   int MT, NT;
   int dbg;             // tuning only: bit0 skip the in-loop global loads / LDS stores, bit1 skip the MFMA block
@@ -122,9 +126,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     for (int j = 0; j < TN; ++j) {
       const int col = wn * (BN / WN) + j * 32 + l31;
       const int rbase = wm * (BM / WM) + i * 32 + 4 * lh;
+      const float al = a.escale ? a.escale[n0 + col] : 1.f, be = a.escale ? a.eshift[n0 + col] : 0.f;
+      const float lo_clamp = (a.erelu && !a.ERES) ? 0.f : -3.0e38f;     // ReLU here unless a residual is added first
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        const float mine_lo = acc[i][j][e], mine_hi = acc[i][j][e + 1];
+        const float mine_lo = fmaxf(acc[i][j][e] * al + be, lo_clamp), mine_hi = fmaxf(acc[i][j][e + 1] * al + be, lo_clamp);
         const float send = odd ? mine_lo : mine_hi;
         const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
         // even lane: row(e), channels (col, col+1) = (mine_lo, neighbour's acc[e]); odd: row(e+1), (col-1, col)
@@ -178,6 +184,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
           const float lo = __uint_as_float(pv[k] << 16) + (((mb >> (2 * k)) & 1u) ? __uint_as_float(po[k] << 16) : 0.f);
           const float hi = __uint_as_float(pv[k] & 0xffff0000u) +
                            (((mb >> (2 * k + 1)) & 1u) ? __uint_as_float(po[k] & 0xffff0000u) : 0.f);
+          res[k] = pack_bf16x2(lo, hi);
+        }
+        v = make_uint4(res[0], res[1], res[2], res[3]);
+      }
+      if (a.ERES) {
+        const uint4 o = *reinterpret_cast<const uint4*>(a.ERES + (size_t)m * a.ldres + n0 + cc * 8);
+        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+        const unsigned* po = reinterpret_cast<const unsigned*>(&o);
+        const float lo_clamp = a.erelu ? 0.f : -3.0e38f;
+        unsigned res[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = fmaxf(__uint_as_float(pv[k] << 16) + __uint_as_float(po[k] << 16), lo_clamp);
+          const float hi = fmaxf(__uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(po[k] & 0xffff0000u), lo_clamp);
           res[k] = pack_bf16x2(lo, hi);
         }
         v = make_uint4(res[0], res[1], res[2], res[3]);
@@ -689,6 +709,7 @@ extern "C" int yv1_conv2d_fwd_nhwc_bf16(const void* x, const void* w, void* y, i
   if (!x || !w || !y || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   ConvArgs a;
   a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
+  a.escale = a.eshift = nullptr; a.ERES = nullptr; a.ldres = 0; a.erelu = 0;
   a.X = (const bf16_t*)x; a.W = (const bf16_t*)w; a.Y = (bf16_t*)y; a.stats = stats;
   a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx;
   a.P = (IH + 2 * pad - k) / stride + 1; a.Q = (IW + 2 * pad - k) / stride + 1;
@@ -700,13 +721,37 @@ extern "C" int yv1_conv2d_fwd_nhwc_bf16(const void* x, const void* w, void* y, i
   return dispatch(a, stream);
 }
 
+// Inference form of the forward convolution: conv + folded eval-mode BatchNorm (scale/shift per output channel) +
+// residual add + ReLU in one launch -- OriginResNet.py:87-107 with the network in eval() mode:
+//   t = bf16(acc * scale[c] + shift[c]);  y = bf16(relu?(t + residual))        (no residual: ReLU before the rounding)
+extern "C" int yv1_conv2d_fwd_bn_act_nhwc_bf16(const void* x, const void* w, void* y, int N, int IH, int IW, int ldx, int Cin,
+                                               int Cout, int ldy, int k, int stride, int pad, const float* scale,
+                                               const float* shift, const void* residual, int ldres, int relu,
+                                               hipStream_t stream) {
+  if (!x || !w || !y || !scale || !shift || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
+  if (residual && ldres % 8) return YV1_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
+  a.X = (const bf16_t*)x; a.W = (const bf16_t*)w; a.Y = (bf16_t*)y; a.stats = nullptr;
+  a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx;
+  a.P = (IH + 2 * pad - k) / stride + 1; a.Q = (IW + 2 * pad - k) / stride + 1;
+  a.Cin = Cin; a.Cout = Cout; a.R = k; a.S = k;
+  a.ah = stride; a.bh = 1; a.ch = -pad; a.aw = stride; a.bw = 1; a.cw = -pad; a.log2d = 0;
+  a.OH = a.P; a.OW = a.Q; a.ldy = ldy; a.os = 1; a.accumulate = 0;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = k; a.Kw = k * k * Cin;
+  a.M = N * a.P * a.Q;
+  a.escale = scale; a.eshift = shift; a.ERES = (const bf16_t*)residual; a.ldres = ldres; a.erelu = relu;
+  return dispatch(a, stream);
+}
+
 // Stem: 7x7 stride-2 pad-3 convolution of the packed NHWC4 image (yv1_pack_input_nhwc4).
 // xp: [N][H+6][W+6][4] bf16; w: [Cout][7][32] bf16 (element s*4+c of row r; zero for c==3 and s==7).
-extern "C" int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy,
-                                        float* stats, hipStream_t stream) {
+static int stem_forward(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy, float* stats,
+                        const float* scale, const float* shift, int relu, hipStream_t stream) {
   if (!xp || !w || !y || N <= 0 || (H & 1) || (W & 1)) return YV1_ERR_BAD_ARG;
   ConvArgs a;
   a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
+  a.escale = scale; a.eshift = shift; a.ERES = nullptr; a.ldres = 0; a.erelu = relu;
   a.X = (const bf16_t*)xp; a.W = (const bf16_t*)w; a.Y = (bf16_t*)y; a.stats = stats;
   a.N = N; a.IH = H + 6; a.IW = W + 6; a.ldx = 4;       // "pixel" = 4 elements; one tap row = 32 contiguous elements
   a.P = H / 2; a.Q = W / 2;
@@ -715,11 +760,22 @@ extern "C" int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, 
   a.OH = a.P; a.OW = a.Q; a.ldy = ldy; a.os = 1; a.accumulate = 0;
   a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = 1; a.wss = 0; a.WS = 1; a.Kw = 7 * 32;
   a.M = N * a.P * a.Q;
-  a.ldx = 4;
   a.dbg = 0;
   if (Cout % 64) return YV1_ERR_UNSUPPORTED;
   // the last tap row of the last pixel reads up to element ((IH-1)*IW + 2*(Q-1))*4 + 31 < IH*IW*4
   return launch<128, 64, 32, 2, 2>(a, stream);
+}
+
+extern "C" int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy,
+                                        float* stats, hipStream_t stream) {
+  return stem_forward(xp, w, y, N, H, W, Cout, ldy, stats, nullptr, nullptr, 0, stream);
+}
+
+// inference form of the stem: + folded eval-mode BatchNorm + ReLU (OriginResNet.py:174-176 in eval mode)
+extern "C" int yv1_conv2d_stem_fwd_bn_act_bf16(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy,
+                                               const float* scale, const float* shift, int relu, hipStream_t stream) {
+  if (!scale || !shift) return YV1_ERR_BAD_ARG;
+  return stem_forward(xp, w, y, N, H, W, Cout, ldy, nullptr, scale, shift, relu, stream);
 }
 
 // Data gradient.  dy: [N,OH,OW,*] (pixel stride lddy, Cout channels); wt: [Cin][k*k][Cout] bf16 (the
@@ -735,6 +791,7 @@ extern "C" int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* 
   const int OH = (IH + 2 * pad - k) / stride + 1, OW = (IW + 2 * pad - k) / stride + 1;
   ConvArgs a;
   a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
+  a.escale = a.eshift = nullptr; a.ERES = nullptr; a.ldres = 0; a.erelu = 0;
   a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx; a.stats = nullptr;
   a.N = N; a.IH = OH; a.IW = OW; a.ldx = lddy;
   a.Cin = Cout; a.Cout = Cin; a.R = k; a.S = k;
@@ -782,6 +839,7 @@ extern "C" int yv1_conv2d_dgrad_add_masked_nhwc_bf16(const void* dy, const void*
   if (!dy || !wt || !dx || !g || !relu_mask || N <= 0) return YV1_ERR_BAD_ARG;
   if (ldg % 8 || Cin % 8) return YV1_ERR_UNSUPPORTED;
   ConvArgs a;
+  a.escale = a.eshift = nullptr; a.ERES = nullptr; a.ldres = 0; a.erelu = 0;
   a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx; a.stats = nullptr;
   a.N = N; a.IH = IH; a.IW = IW; a.ldx = lddy;
   a.Cin = Cout; a.Cout = Cin; a.R = 1; a.S = 1;

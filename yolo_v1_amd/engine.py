@@ -79,6 +79,7 @@ class HipBackbone(nn.Module):
         self._grad_ready_hook = None
         self._phase_boundary = None
         self.wgrad_side_stream = os.environ.get("YV1_WGRAD_SIDE_STREAM", "1") != "0"
+        self.fused_eval = os.environ.get("YV1_FUSED_EVAL", "1") != "0"   # eval(): BatchNorm folded into the conv epilogue
 
     def set_grad_ready_hook(self, fn):
         """``fn([(param, grad), ...])`` is called from inside the backward executor as soon as the

@@ -149,6 +149,22 @@ def conv_fwd(x, w, y, want_stats=True):
     return stats
 
 
+def conv_fwd_bn_act(x, w, y, st, relu=True, residual=None):
+    """Inference: y = relu?(bf16(conv(x, w) * scale + shift) + residual), ``st`` an eval-mode BNState."""
+    dev = x.t.device
+    check(lib().yv1_conv2d_fwd_bn_act_nhwc_bf16(x.p, ptr(w.fwd), y.p, x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, y.ld, w.k, w.stride,
+                                                w.pad, ptr(st.scale), ptr(st.shift),
+                                                residual.p if residual is not None else None,
+                                                residual.ld if residual is not None else 0, 1 if relu else 0,
+                                                stream_ptr(dev)), "yv1_conv2d_fwd_bn_act_nhwc_bf16")
+
+
+def stem_fwd_bn_act(xp, w, y, H, W, st, relu=True):
+    dev = xp.device
+    check(lib().yv1_conv2d_stem_fwd_bn_act_bf16(ptr(xp), ptr(w.fwd), y.p, y.N, H, W, w.O, y.ld, ptr(st.scale), ptr(st.shift),
+                                                1 if relu else 0, stream_ptr(dev)), "yv1_conv2d_stem_fwd_bn_act_bf16")
+
+
 def pack_input(images):
     """NCHW fp32 -> zero-padded NHWC4 bf16 [N][H+6][W+6][4]."""
     N, C, H, W = images.shape
