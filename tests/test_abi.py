@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -62,3 +64,25 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
         yu.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
     with pytest.raises(_lib.Yv1Error):
         YOLOLossV1(1, 7, 2, 20, _quiet=True)(torch.zeros(1, 7, 7, 30), torch.zeros(1, 7, 7, 30))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/yv1.h must be consumable by a C compiler (the boundary is a C ABI: no C++ types, no torch types) and a C
+    translation unit must be able to take the address of every declared entry point."""
+    import re
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc in this image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "yv1.h")).read()
+    names = re.findall(r"^(?:int|size_t)\s+(yv1_\w+)\s*\(", hdr, re.M)
+    assert len(names) >= 40
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "yv1.h"\n#include <stddef.h>\nvoid* table[] = {\n' +
+                   "".join("  (void*)%s,\n" % n for n in names) + "};\nint count(void) { return (int)(sizeof table / sizeof table[0]); }\n")
+    obj = tmp_path / "use_header.o"
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-Wno-pedantic", "-c", str(src), "-o", str(obj),
+                           "-I" + os.path.join(root, "include")])
+    assert obj.exists()
