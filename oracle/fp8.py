@@ -62,8 +62,8 @@ def conv_fused(x8, w, scale=None, shift=None, residual=None, relu=True, stride=1
 def resnet50_eval_fp8(x, P, S=7, trace=None):
     """x [N,3,H,W] fp32 -> pred [N,H/32 (S=14) or H/64 (S=7), ., B*5+C].  ``trace`` (a list) collects the e4m3
     block outputs as (label, e4m3 values, bf16 values), NCHW fp32 tensors."""
-    y0 = bf16(F.conv2d(bf16(x), bf16(P["conv1.weight"]), stride=2, padding=3))
-    s0, b0 = bn_coeffs(P, "bn1")
+    y0 = F.conv2d(bf16(x), bf16(P["conv1.weight"]), stride=2, padding=3)      # BatchNorm + ReLU ride in the stem's epilogue:
+    s0, b0 = bn_coeffs(P, "bn1")                                                 # one bf16 rounding, after the ReLU
     z0 = bf16(F.relu(y0 * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1)))
     x16 = F.max_pool2d(z0, 3, 2, 1)
     x8 = e4m3(x16)

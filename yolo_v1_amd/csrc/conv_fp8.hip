@@ -412,7 +412,14 @@ extern "C" int yv1_conv2d_fwd_nhwc_fp8(const void* x8, const void* w8, const flo
   a.M = N * a.P * a.Q;
   if ((long long)N * IH * IW * ldx >= (1ll << 31) || (long long)Cout * k * k * Cin >= (1ll << 31)) return YV1_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  return (Cin % 128 == 0) ? dispatch8<128>(a, st) : dispatch8<64>(a, st);
+  // K-step: 64 bytes with three stages (48 KB, 3 workgroups/CU) by default; 128 bytes with two stages on the deep 3x3
+  // layers (same rule as conv.hip).  Tuning: YV1_FP8_BKB=64|128 forces one.
+  static int fbk = -1;
+  if (fbk < 0) { const char* e = getenv("YV1_FP8_BKB"); fbk = e ? atoi(e) : 0; }
+  bool d128 = Cin % 128 == 0 && ((k > 1 && a.M < 250000) || (Cin >= 2048 && a.M < 150000));
+  if (fbk == 64) d128 = false;
+  if (fbk == 128) d128 = Cin % 128 == 0;
+  return d128 ? dispatch8<128>(a, st) : dispatch8<64>(a, st);
 }
 
 extern "C" int yv1_quantize_bf16_to_fp8(const void* x, int ldx, void* y8, int ldy, long long npix, int C,

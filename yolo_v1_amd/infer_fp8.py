@@ -147,8 +147,7 @@ class ResNetFp8:
         w0 = net.cw(net.conv1, stem=True)
         xp = ops.pack_input(images)
         y0 = ops.new_act(N, H // 2, W // 2, 64, dev)
-        ops.stem_fwd(xp, w0, y0, H, W)
-        ops.bn_apply(y0, self.stem_bn, y0, relu=True)
+        ops.stem_fwd_bn_act(xp, w0, y0, H, W, self.stem_bn, relu=True)      # BatchNorm + ReLU in the stem's epilogue
         pooled = ops.new_act(N, H // 4, W // 4, 64, dev)
         ops.maxpool_fwd(y0, pooled)
         x8 = quantize(pooled)
