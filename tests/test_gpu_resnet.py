@@ -306,9 +306,11 @@ def test_data_parallel_graphed_step_two_graphs_is_bitwise_the_eager_step():
             dist.destroy_process_group()
 
 
-def test_batched_eval_loop_matches_per_image_oracle_pipeline():
+@pytest.mark.parametrize("fp8", [False, True])
+def test_batched_eval_loop_matches_per_image_oracle_pipeline(fp8):
     """run_test_mAP (batched forward + batched GPU decoder/NMS + host voc_eval) against the reference's
-    per-image pipeline restated with the oracle decoder and oracle voc_eval on the same network outputs."""
+    per-image pipeline restated with the oracle decoder and oracle voc_eval on the same network outputs -- for the bf16
+    eval-mode network and for the fp8 inference executor (BASELINE config 5: fp8 conv + batched eval NMS)."""
     from collections import defaultdict
     from oracle import boxes as obx
     from oracle import voc as ov
@@ -317,6 +319,9 @@ def test_batched_eval_loop_matches_per_image_oracle_pipeline():
     from yolo_v1_amd.utils.YOLODataLoader import yoloDataset
     torch.manual_seed(3)
     net = resnet50(S=7).to(DEV).eval()
+    if fp8:
+        from yolo_v1_amd.infer_fp8 import ResNetFp8
+        net = ResNetFp8(net)
     ds = yoloDataset(None, train=False, with_file_path=True, S=7, length=10, image_size=128)
     target = ds.synthetic_ground_truth()
 

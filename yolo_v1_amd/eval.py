@@ -27,6 +27,7 @@ def main(argv=None):
     ap.add_argument("--list-file", default=None, help="VOC image list (labels next to the images); default: synthetic")
     ap.add_argument("--num", type=int, default=256)
     ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--fp8", action="store_true", help="ResNet only: run the forward on the fp8 (e4m3) MFMA executor")
     args = ap.parse_args(argv)
     device = "cuda:0"
     if args.backbone == "resnet":
@@ -39,6 +40,12 @@ def main(argv=None):
     if args.checkpoint:
         load_checkpoint(net, args.checkpoint, device)
     net.eval()
+    model = net
+    if args.fp8:
+        if args.backbone != "resnet":
+            raise SystemExit("--fp8: the fp8 executor covers the ResNet backbone")
+        from .infer_fp8 import ResNetFp8
+        model = ResNetFp8(net)
     if args.list_file:
         ds = yoloDataset(args.list_file, train=False, with_file_path=True, S=args.S)
         target = prep_test_data(args.list_file, little_test=args.num)
@@ -46,7 +53,7 @@ def main(argv=None):
         ds = yoloDataset(None, train=False, with_file_path=True, S=args.S, length=args.num)
         target = ds.synthetic_ground_truth()
     t0 = time.perf_counter()
-    m = run_test_mAP(net, target, ds, len(ds), S=args.S, device=device, little_test=args.num, batch_size=args.batch_size)
+    m = run_test_mAP(model, target, ds, len(ds), S=args.S, device=device, little_test=args.num, batch_size=args.batch_size)
     dt = time.perf_counter() - t0
     print("mAP %.5f over %d images, %.1f img/s (batched forward + GPU decoder/NMS)" % (m, min(args.num, len(ds)), min(args.num, len(ds)) / dt))
 
