@@ -42,7 +42,7 @@ struct ConvArgs {
   const bf16_t* X;
   const bf16_t* W;
   bf16_t* Y;
-  float* stats;        // [MT][2][Cout] partial sums, or nullptr
+  float* stats = nullptr;   // [MT][2][Cout] partial sums, or nullptr
   int N, IH, IW, ldx;  // source tensor: pixel stride ldx elements
   int P, Q;            // GEMM pixel grid per image
   int Cin, Cout;       // K per tap, GEMM N
@@ -52,17 +52,17 @@ struct ConvArgs {
   int oh0, ow0;
   int wr0, wrs, ws0, wss, WS;   // weight tap of loop tap (r,s): (wr0 + r*wrs)*WS + (ws0 + s*wss)
   int Kw;                       // elements per weight row (= all filter taps x Cin)
-  int accumulate;
-  const bf16_t* AS;             // optional: out += AM-bit ? AS[m][n] : 0 (shortcut gradient through a ReLU, see
-  const unsigned char* AM;      //           yv1_conv2d_dgrad_add_masked_nhwc_bf16); AM is [M][ldam] bytes, bit k of
-  int ldas, ldam;               //           byte j = channel 8j+k
-  const float* escale;          // optional inference epilogue: t = bf16(acc * escale[n] + eshift[n]) (folded eval-mode
-  const float* eshift;          //   BatchNorm), out = t + ERES (bf16 residual), ReLU if erelu
-  const bf16_t* ERES;
-  int ldres, erelu;
+  int accumulate = 0;
+  const bf16_t* AS = nullptr;   // optional: out += AM-bit ? AS[m][n] : 0 (shortcut gradient through a ReLU, see
+  const unsigned char* AM = nullptr;   //        yv1_conv2d_dgrad_add_masked_nhwc_bf16); AM is [M][ldam] bytes, bit k of
+  int ldas = 0, ldam = 0;       //           byte j = channel 8j+k
+  const float* escale = nullptr;   // optional inference epilogue: t = bf16(acc * escale[n] + eshift[n]) (folded eval-mode
+  const float* eshift = nullptr;   //   BatchNorm), out = t + ERES (bf16 residual), ReLU if erelu
+  const bf16_t* ERES = nullptr;
+  int ldres = 0, erelu = 0;
   int M;
   int MT, NT;
-  int dbg;             // tuning only: bit0 skip the in-loop global loads / LDS stores, bit1 skip the MFMA block
+  int dbg = 0;         // tuning only: bit0 skip the in-loop global loads / LDS stores, bit1 skip the MFMA block
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
