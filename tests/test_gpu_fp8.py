@@ -5,7 +5,6 @@ inputs and must be BIT-EXACT; the fused convolution differs from the oracle only
 so a bf16 output may differ by one bf16 ulp (2^-8 relative) on a small fraction of elements and an e4m3 output by one
 e4m3 ulp (2^-3 relative) on a smaller one; the whole network (54 quantised layers) is checked on the sigmoid outputs.
 """
-import numpy as np
 import pytest
 import torch
 

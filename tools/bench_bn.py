@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from yolo_v1_amd import ops, _lib
+from yolo_v1_amd import ops
 from yolo_v1_amd._lib import lib, ptr, stream_ptr, check
 DEV = "cuda:0"
 N = 64

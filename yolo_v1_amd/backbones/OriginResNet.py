@@ -16,7 +16,6 @@ Per Bottleneck (OriginResNet.py:87-107), forward:
     yd = conv1x1(x, stride)    projection shortcut when the shape changes (:159-163)
     out = relu(bn3(y3) + (bn_d(yd) | x))      one fused elementwise kernel
 """
-import torch
 import torch.nn as nn
 
 from .. import _lib, ops

@@ -8,9 +8,8 @@ used (smoke / throughput only: random weights give mAP ~ 0).
 import argparse
 import time
 
-import torch
 
-from .utils.utils import create_logger, prep_test_data, run_test_mAP
+from .utils.utils import prep_test_data, run_test_mAP
 from .utils.YOLODataLoader import yoloDataset
 
 

@@ -15,7 +15,6 @@
 ``DevicePrefetcher`` feeds the training loop: pinned staging buffers, H2D copies and the device encoder on a
 copy stream, one batch ahead of the step that is running.
 """
-import math
 
 import torch
 import torch.utils.data as data
