@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-sgd", type=int, default=1)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--fp8-forward", action="store_true",
+                    help="BASELINE config 5: forward convolutions on the fp8 (e4m3) MFMA path, bf16 backward (ResNet only; "
+                         "NOT the headline configuration, which computes in bf16)")
     args = ap.parse_args()
 
     from yolo_v1_amd import distributed as ydist
@@ -87,6 +90,10 @@ def main():
     torch.manual_seed(0)
     net, loss_layer, opt = build(args.backbone, args.S, 2, 20, args.batch, device, quiet=True,
                                  fused_optimizer=bool(args.fused_sgd))
+    if args.fp8_forward:
+        if args.backbone != "resnet":
+            raise SystemExit("--fp8-forward: the fp8 forward path covers the ResNet backbone")
+        net.fp8_forward = True
     use_dist = torch.distributed.is_initialized()
     sync = ydist.GradSync(net) if use_dist else None
     if use_dist:                                 # same initial weights on every rank
@@ -148,7 +155,8 @@ def main():
             else "images/sec training (%s 448^2, S=%d)" % (args.backbone, args.S),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8-e4m3 forward GEMMs, bf16 backward" if args.fp8_forward else "bf16",
+            "data": "synthetic",
             "config": {"workload": "%s 448x448 S=%d B=2 C=20 bf16, per-GPU batch %d, fwd+loss+bwd+SGD(momentum 0.99)%s"
                                    % ("ResNet-50" if args.backbone == "resnet" else "DenseNet-121", args.S, args.batch,
                                       "+RCCL grad all-reduce" if world > 1 else ""),

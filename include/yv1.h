@@ -57,6 +57,16 @@ int yv1_decode_nms_batched(const float* pred, int N, int S, int B, int C, double
 int yv1_conv2d_fwd_nhwc_fp8(const void* x8, const void* w8, const float* alpha, const float* beta, const void* residual,
                             int ldr, void* y_bf16, int ld16, void* y_fp8, int ld8, int N, int IH, int IW, int ldx, int Cin,
                             int Cout, int k, int stride, int pad, int relu, yv1_stream_t stream);
+/* training form ("fp8 forward GEMMs, bf16 backward"): y = bf16(acc * alpha[c]), alpha = 1/q from
+ * yv1_prep_weights_fp8_multi, zero_beta = Cout zeros; stats: yv1_conv2d_fp8_stats_rows(M, Cout) rows of [2][Cout]
+ * partial sums for yv1_bn_finalize, as yv1_conv2d_fwd_nhwc_bf16 writes them */
+int yv1_conv2d_fp8_stats_rows(int M, int Cout);
+int yv1_conv2d_fwd_stats_nhwc_fp8(const void* x8, const void* w8, const float* alpha, const float* zero_beta, void* y,
+                                  int ldy, float* stats, int N, int IH, int IW, int ldx, int Cin, int Cout, int k,
+                                  int stride, int pad, yv1_stream_t stream);
+int yv1_prep_weights_fp8_max_tensors(void);
+int yv1_prep_weights_fp8_multi(const float* const* w, const long long* strides, const int* O, const int* I, const int* k,
+                               void* const* w8, float* const* alpha, int n, yv1_stream_t stream);
 /* bf16 NHWC -> e4m3 NHWC (saturating at +-448), C % 8 == 0 */
 int yv1_quantize_bf16_to_fp8(const void* x, int ldx, void* y8, int ldy, long long npix, int C, yv1_stream_t stream);
 /* fp32 OIHW (element strides so,si,sh,sw) -> e4m3 [Opad][k*k][Ipad]; q[o] (Opad floats) = the power of two each
@@ -131,6 +141,11 @@ int yv1_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float
 int yv1_bn_apply(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
                  const float* shift, const float* res_scale, const float* res_shift, long long npix, int C, int relu,
                  void* relu_mask, yv1_stream_t stream);
+/* the same with a second, e4m3 copy of z (pixel stride ldz8 bytes): the operand of the next fp8 convolution */
+int yv1_bn_apply_q8(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
+                 const float* shift, const float* res_scale, const float* res_shift, long long npix, int C, int relu,
+                 void* relu_mask, void* z8, int ldz8,
+                    yv1_stream_t stream);
 int yv1_bn_reduce_rows(long long npix, int C);
 int yv1_bn_stats(const void* y, int ldy, long long npix, int C, float* partials, yv1_stream_t stream);
 /* mask_mode: 0 none, 1 ReLU mask from z > 0, 2 from scale*y+shift > 0, 3 z is yv1_bn_apply's relu_mask (ldz = C/8 bytes) */

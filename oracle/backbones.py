@@ -135,21 +135,29 @@ def _bn(x, P, name, training, momentum=0.1, eps=1e-5):
     return F.batch_norm(x, rm, rv, P[name + ".weight"], P[name + ".bias"], training, momentum, eps)
 
 
-def bottleneck(x, P, p, stride, training=True, q=None):
-    """OriginResNet.py:87-107 (stride on the 3x3, :79)."""
+def bottleneck(x, P, p, stride, training=True, q=None, qconv=None):
+    """OriginResNet.py:87-107 (stride on the 3x3, :79).  ``qconv`` (optional) replaces each convolution:
+    ``qconv(conv_fn, x, w_master, w_stored)`` -- used to emulate a forward GEMM that reads lower-precision copies of its
+    operands while the backward keeps the stored ones (oracle/fp8.py::fp8_forward_ste)."""
     w = lambda k: _q(P[p + k], q)
-    out = _q(F.relu(_bn(_q(F.conv2d(x, w(".conv1.weight")), q), P, p + ".bn1", training)), q)
-    out = _q(F.relu(_bn(_q(F.conv2d(out, w(".conv2.weight"), stride=stride, padding=1), q), P, p + ".bn2", training)), q)
-    out = _bn(_q(F.conv2d(out, w(".conv3.weight")), q), P, p + ".bn3", training)
+
+    def conv(inp, wk, **kw):
+        if qconv is not None:
+            return qconv(lambda a, b: F.conv2d(a, b, **kw), inp, P[p + wk], w(wk))
+        return F.conv2d(inp, w(wk), **kw)
+    out = _q(F.relu(_bn(_q(conv(x, ".conv1.weight"), q), P, p + ".bn1", training)), q)
+    out = _q(F.relu(_bn(_q(conv(out, ".conv2.weight", stride=stride, padding=1), q), P, p + ".bn2", training)), q)
+    out = _bn(_q(conv(out, ".conv3.weight"), q), P, p + ".bn3", training)
     if (p + ".downsample.0.weight") in P:
-        idt = _bn(_q(F.conv2d(x, w(".downsample.0.weight"), stride=stride), q), P, p + ".downsample.1", training)
+        idt = _bn(_q(conv(x, ".downsample.0.weight", stride=stride), q), P, p + ".downsample.1", training)
     else:
         idt = x
     return _q(F.relu(out + idt), q)
 
 
-def resnet50_forward(x, P, S=7, training=True, q=None):
-    """OriginResNet.py:173-195.  x [N,3,H,W] -> [N,H/64 or H/32, ., B*5+C]."""
+def resnet50_forward(x, P, S=7, training=True, q=None, qconv=None):
+    """OriginResNet.py:173-195.  x [N,3,H,W] -> [N,H/64 or H/32, ., B*5+C].  ``qconv``: see ``bottleneck`` (the stem and
+    the head are left alone)."""
     x = _q(F.conv2d(_q(x, q), _q(P["conv1.weight"], q), stride=2, padding=3), q)
     x = _q(F.relu(_bn(x, P, "bn1", training)), q)
     x = F.max_pool2d(x, 3, 2, 1)
@@ -158,7 +166,7 @@ def resnet50_forward(x, P, S=7, training=True, q=None):
         stages.append(("layer5", 3, 2))
     for name, blocks, stride in stages:
         for i in range(blocks):
-            x = bottleneck(x, P, "%s.%d" % (name, i), stride if i == 0 else 1, training, q)
+            x = bottleneck(x, P, "%s.%d" % (name, i), stride if i == 0 else 1, training, q, qconv)
     x = _q(F.conv2d(x, _q(P["layer6.weight"], q)), q)
     x = _bn(x, P, "bn_end", training)
     return torch.sigmoid(x).permute(0, 2, 3, 1)

@@ -37,6 +37,18 @@ def quantize_weight(w):
     return e4m3(w * q.view(-1, 1, 1, 1)), q
 
 
+def fp8_forward_ste(conv_fn, x, w_master, w_stored):
+    """``qconv`` hook for ``backbones.resnet50_forward``: training with fp8 forward GEMMs and a bf16 backward.
+    Forward VALUE: the convolution of the e4m3 copy (scale 1) of the stored bf16 activation with the per-output-channel
+    scaled e4m3 weights (quantised from the fp32 master weight, as the HIP path does).  GRADIENTS: those of the
+    convolution of the stored bf16 operands -- the HIP backward reads the bf16 activations and weights."""
+    y = conv_fn(x, w_stored)
+    with torch.no_grad():
+        w8, q = quantize_weight(w_master)
+        yq = conv_fn(e4m3(bf16(x)), w8 / q.view(-1, 1, 1, 1))
+    return y + (yq - y).detach()
+
+
 def bn_coeffs(P, name):
     invstd = torch.rsqrt(P[name + ".running_var"] + EPS)
     scale = P[name + ".weight"] * invstd

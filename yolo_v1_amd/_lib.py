@@ -35,6 +35,11 @@ SIGNATURES = {
     # conv_fp8.hip
     "yv1_conv2d_fwd_nhwc_fp8": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                       c_i, c_i, c_i, c_p]),
+    "yv1_conv2d_fp8_stats_rows": (c_i, [c_i, c_i]),
+    "yv1_conv2d_fwd_stats_nhwc_fp8": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                            c_p]),
+    "yv1_prep_weights_fp8_max_tensors": (c_i, []),
+    "yv1_prep_weights_fp8_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "yv1_quantize_bf16_to_fp8": (c_i, [c_p, c_i, c_p, c_i, c_ll, c_i, c_p]),
     "yv1_prep_weights_fp8": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "yv1_fp8_fold_bn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
@@ -59,6 +64,7 @@ SIGNATURES = {
     "yv1_bn_finalize": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yv1_bn_eval_coeffs": (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
     "yv1_bn_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p]),
+    "yv1_bn_apply_q8": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_i, c_p]),
     "yv1_bn_reduce_rows": (c_i, [c_ll, c_i]),
     "yv1_bn_stats": (c_i, [c_p, c_i, c_ll, c_i, c_p, c_p]),
     "yv1_bn_bwd_reduce": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p]),

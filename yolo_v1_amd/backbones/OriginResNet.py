@@ -127,6 +127,21 @@ class ResNet(HipBackbone):
             return ops.bn_eval_state(bn)
 
         rec = {"blocks": []}
+        # fp8 forward GEMMs (training, BASELINE config 5): every Bottleneck convolution reads e4m3 copies of its input
+        # and weights; the copies are written by the BN-apply that produces the activation.  Everything the backward
+        # reads (raw conv outputs, bf16 activations, bf16 weights) is unchanged.
+        f8 = bool(train and self.fp8_forward)
+        if f8:
+            self.refresh_all_weights_fp8()
+
+        def conv(xa, xa8, cp, ya):
+            if f8:
+                return ops.conv_fwd_fp8(xa8, self.cw8(cp), ya, train)
+            return ops.conv_fwd(xa, self.cw(cp), ya, train)
+
+        def q8(act):
+            return ops.Fp8Act(act.N, act.H, act.W, act.C, dev) if f8 else None
+
         # stem: 7x7/2 conv -> BN -> ReLU -> maxpool 3x3/2                       (:174-177)
         w0 = self.cw(self.conv1, stem=True)
         xp = ops.pack_input(images)
@@ -136,34 +151,36 @@ class ResNet(HipBackbone):
         ops.bn_apply(y0, s0, z0, relu=True)
         x = ops.new_act(N, H // 4, W // 4, 64, dev)
         pidx = ops.maxpool_fwd(z0, x, want_index=save)
+        x8 = ops.quantize_fp8(x) if f8 else None
         rec["stem"] = (xp, y0, s0, z0, H, W, pidx)
 
         for blk in self._blocks():
-            w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
             planes = blk.conv1.out_channels
             y1 = ops.new_act(N, x.H, x.W, planes, dev)
-            s1 = norm(ops.conv_fwd(x, w1, y1, train), y1.npix, blk.bn1)
+            s1 = norm(conv(x, x8, blk.conv1, y1), y1.npix, blk.bn1)
             z1 = ops.new_act(N, x.H, x.W, planes, dev)
-            ops.bn_apply(y1, s1, z1, relu=True)
+            z1_8 = q8(z1)
+            ops.bn_apply(y1, s1, z1, relu=True, z8=z1_8)
             h2, w2_ = ops.conv_out_hw(x.H, x.W, 3, blk.stride, 1)
             y2 = ops.new_act(N, h2, w2_, planes, dev)
-            s2 = norm(ops.conv_fwd(z1, w2, y2, train), y2.npix, blk.bn2)
+            s2 = norm(conv(z1, z1_8, blk.conv2, y2), y2.npix, blk.bn2)
             z2 = ops.new_act(N, h2, w2_, planes, dev)
-            ops.bn_apply(y2, s2, z2, relu=True)
+            z2_8 = q8(z2)
+            ops.bn_apply(y2, s2, z2, relu=True, z8=z2_8)
             y3 = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
-            s3 = norm(ops.conv_fwd(z2, w3, y3, train), y3.npix, blk.bn3)
+            s3 = norm(conv(z2, z2_8, blk.conv3, y3), y3.npix, blk.bn3)
             out = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
+            out8 = q8(out)
             yd = sd = None
             if blk.downsample is not None:
-                wd = self.cw(blk.downsample[0])
                 yd = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
-                sd = norm(ops.conv_fwd(x, wd, yd, train), yd.npix, blk.downsample[1])
-                omask = ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd, want_mask=save)
+                sd = norm(conv(x, x8, blk.downsample[0], yd), yd.npix, blk.downsample[1])
+                omask = ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd, want_mask=save, z8=out8)
             else:
-                omask = ops.bn_apply(y3, s3, out, relu=True, residual=x, want_mask=save)
+                omask = ops.bn_apply(y3, s3, out, relu=True, residual=x, want_mask=save, z8=out8)
             if save:
                 rec["blocks"].append((blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask))
-            x = out
+            x, x8 = out, out8
 
         # head: 1x1 conv -> bn_end -> sigmoid, already NHWC                      (:186-189)
         wh = self.cw(self.layer6)

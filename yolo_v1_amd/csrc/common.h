@@ -36,6 +36,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 
+// four fp32 -> four OCP e4m3 bytes (round to nearest even; inputs clamped to the finite range +-448 first)
+__device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+
 // 64-lane wavefront reductions (CDNA wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -35,6 +35,7 @@ struct Conv8Args {
   const bf16_t* R;       // residual [M][ldr] bf16 or nullptr
   bf16_t* Y16;           // [M][ld16] or nullptr
   unsigned char* Y8;     // [M][ld8] or nullptr
+  float* stats = nullptr;   // training form: [MT][2][Cout] partial sums of t and t*t (BatchNorm batch statistics)
   int ldr, ld16, ld8;
   int N, IH, IW, ldx;    // input pixel stride in bytes (= channels)
   int P, Q, Cin, Cout, KS, stride, pad, relu;
@@ -216,10 +217,28 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
   // ---- epilogue 1: t = bf16(acc * alpha + beta), staged through LDS (layout and DPP pairing as in conv.hip)
   unsigned char* et = smem;
   const bool odd = lane & 1;
+  float* red = reinterpret_cast<float*>(smem + BM * EPI_PITCH);     // [WM][2][BN], behind the staging tile
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = wn * (BN / WN) + j * 32 + l31;
     const float al = a.alpha[n0 + col], be = a.beta[n0 + col];
+    if (a.stats) {                         // per-channel sum / sum of squares of the fp32 results (rows past M hold 0)
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][j][e] * al;      // beta is 0 in the training form
+          s += v;
+          ss += v * v;
+        }
+      s += __shfl_xor(s, 32, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lh == 0) {
+        red[(wm * 2 + 0) * BN + col] = s;
+        red[(wm * 2 + 1) * BN + col] = ss;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int rbase = wm * (BM / WM) + i * 32 + 4 * lh;
@@ -236,6 +255,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
     }
   }
   __syncthreads();
+  if (a.stats && tid < BN) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { s += red[(w * 2 + 0) * BN + tid]; ss += red[(w * 2 + 1) * BN + tid]; }
+    float* o = a.stats + (size_t)mt * 2 * a.Cout + n0 + tid;
+    o[0] = s;
+    o[a.Cout] = ss;
+  }
 
   // ---- epilogue 2: residual add + ReLU on full 16-B channel runs; bf16 and/or e4m3 stores
   constexpr int OCPR = BN / 8;
@@ -293,7 +320,7 @@ template <int BM, int BN, int BKB, int WM, int WN, int NST>
 int launch8(Conv8Args& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BKB;
   constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
-  constexpr int EPI = BM * EPI_PITCH;
+  constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
   constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
@@ -384,6 +411,63 @@ __global__ void __launch_bounds__(256) k_prep_weights_fp8(const float* __restric
   }
 }
 
+// Multi-tensor form of k_prep_weights_fp8 for the training path (the weights change every step): one launch
+// quantises up to PREP8_MAX convolutions; workgroup -> (tensor, output channel) through a prefix table.  Writes
+// alpha[o] = 1 / q[o] directly (no BatchNorm to fold in training mode).
+constexpr int PREP8_MAX = 16;
+struct Prep8Table {
+  const float* w[PREP8_MAX];
+  unsigned char* w8[PREP8_MAX];
+  float* alpha[PREP8_MAX];
+  long long so[PREP8_MAX], si[PREP8_MAX], sh[PREP8_MAX], sw[PREP8_MAX];
+  int O[PREP8_MAX], I[PREP8_MAX], KS[PREP8_MAX], first_block[PREP8_MAX + 1];
+  int count;
+};
+
+__global__ void __launch_bounds__(256) k_prep_weights_fp8_multi(Prep8Table t) {
+  int ti = 0;
+  while (ti + 1 < t.count && (int)blockIdx.x >= t.first_block[ti + 1]) ++ti;
+  const int o = blockIdx.x - t.first_block[ti];
+  const float* __restrict__ w = t.w[ti];
+  const long long so = t.so[ti], si = t.si[ti], sh = t.sh[ti], sw = t.sw[ti];
+  const int O = t.O[ti], I = t.I[ti], KS = t.KS[ti];
+  const int taps = KS * KS, total = taps * I;
+  __shared__ float red[4];
+  __shared__ float qs;
+  float amax = 0.f;
+  if (o < O)
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+      const int tap = idx / I, i = idx - tap * I;
+      amax = fmaxf(amax, fabsf(w[o * so + i * si + (tap / KS) * sh + (tap % KS) * sw]));
+    }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float q = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(448.f / m, &e);
+      q = ldexpf(1.f, min(max(e - 1, -100), 100));
+    }
+    qs = q;
+    t.alpha[ti][o] = o < O ? 1.f / q : 0.f;              // q is a power of two: exact
+  }
+  __syncthreads();
+  const float q = qs;
+  unsigned char* w8 = t.w8[ti];
+  for (int idx = threadIdx.x * 4; idx < total; idx += 256 * 4) {
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int id = idx + k, tap = id / I, i = id - tap * I;
+      f[k] = o < O ? w[o * so + i * si + (tap / KS) * sh + (tap % KS) * sw] * q : 0.f;
+    }
+    *reinterpret_cast<unsigned*>(w8 + (size_t)o * total + idx) = pack_fp8x4(f[0], f[1], f[2], f[3]);
+  }
+}
+
 __global__ void k_fold_fp8(const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ q,
                            int C, int Cpad, float* __restrict__ alpha, float* __restrict__ beta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -422,6 +506,39 @@ extern "C" int yv1_conv2d_fwd_nhwc_fp8(const void* x8, const void* w8, const flo
   return d128 ? dispatch8<128>(a, st) : dispatch8<64>(a, st);
 }
 
+// Training form of the forward: y = bf16(acc * alpha[c]) with alpha = 1/q[c] (the weight dequantisation only) plus the
+// BatchNorm batch-statistic partials of the fp32 results, like yv1_conv2d_fwd_nhwc_bf16 -- "fp8 forward GEMMs,
+// bf16 backward" (the backward keeps using the bf16 activations and weights).
+static int fp8_tile_bm(int M, int Cout) {
+  const long long tiles128 = (long long)((M + 127) / 128) * ((Cout + 127) / 128);
+  if (Cout % 128 == 0 && tiles128 >= 192) return 128;
+  const long long tiles = (long long)((M + 127) / 128) * (Cout / 64);
+  return tiles >= 512 ? 128 : 64;
+}
+
+extern "C" int yv1_conv2d_fp8_stats_rows(int M, int Cout) {
+  const int bm = fp8_tile_bm(M, Cout);
+  return (M + bm - 1) / bm;
+}
+
+extern "C" int yv1_conv2d_fwd_stats_nhwc_fp8(const void* x8, const void* w8, const float* alpha, const float* zero_beta,
+                                             void* y, int ldy, float* stats, int N, int IH, int IW, int ldx, int Cin,
+                                             int Cout, int k, int stride, int pad, yv1_stream_t stream) {
+  if (!x8 || !w8 || !alpha || !zero_beta || !y || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
+  if (Cin % 64 || Cout % 64 || ldx % 16 || ldy % 8) return YV1_ERR_UNSUPPORTED;
+  Conv8Args a;
+  a.X = (const unsigned char*)x8; a.W = (const unsigned char*)w8; a.alpha = alpha; a.beta = zero_beta;
+  a.R = nullptr; a.ldr = 0; a.Y16 = (bf16_t*)y; a.ld16 = ldy; a.Y8 = nullptr; a.ld8 = 0; a.stats = stats;
+  a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx;
+  a.P = (IH + 2 * pad - k) / stride + 1; a.Q = (IW + 2 * pad - k) / stride + 1;
+  a.Cin = Cin; a.Cout = Cout; a.KS = k; a.stride = stride; a.pad = pad; a.relu = 0;
+  a.M = N * a.P * a.Q;
+  if ((long long)N * IH * IW * ldx >= (1ll << 31) || (long long)Cout * k * k * Cin >= (1ll << 31)) return YV1_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const bool d128 = Cin % 128 == 0 && ((k > 1 && a.M < 250000) || (Cin >= 2048 && a.M < 150000));
+  return d128 ? dispatch8<128>(a, st) : dispatch8<64>(a, st);
+}
+
 extern "C" int yv1_quantize_bf16_to_fp8(const void* x, int ldx, void* y8, int ldy, long long npix, int C,
                                         yv1_stream_t stream) {
   if (!x || !y8 || npix < 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8) return YV1_ERR_BAD_ARG;
@@ -439,6 +556,30 @@ extern "C" int yv1_prep_weights_fp8(const float* w, long long so, long long si, 
   if (!w || !w8 || !q || O <= 0 || I <= 0 || k <= 0 || Opad < O || Ipad < I || (k * k * Ipad) % 4) return YV1_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_prep_weights_fp8, dim3(Opad), dim3(256), 0, (hipStream_t)stream, w, so, si, sh, sw, O, I, k, Ipad,
                      (unsigned char*)w8, q);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_prep_weights_fp8_max_tensors(void) { return PREP8_MAX; }
+
+// n <= yv1_prep_weights_fp8_max_tensors() bias-free conv weights (fp32 OIHW, element strides strides[4*i..]) ->
+// w8[i]: e4m3 [Opad][k*k][I] (Opad = O rounded up to 64), alpha[i]: Opad floats = 1/q per output channel
+extern "C" int yv1_prep_weights_fp8_multi(const float* const* w, const long long* strides, const int* O, const int* I,
+                                          const int* k, void* const* w8, float* const* alpha, int n, yv1_stream_t stream) {
+  if (!w || !strides || !O || !I || !k || !w8 || !alpha || n <= 0 || n > PREP8_MAX) return YV1_ERR_BAD_ARG;
+  Prep8Table t;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || !w8[i] || !alpha[i] || O[i] <= 0 || I[i] <= 0 || k[i] <= 0 || (k[i] * k[i] * I[i]) % 4) return YV1_ERR_BAD_ARG;
+    t.w[i] = w[i]; t.w8[i] = (unsigned char*)w8[i]; t.alpha[i] = alpha[i];
+    t.so[i] = strides[4 * i]; t.si[i] = strides[4 * i + 1]; t.sh[i] = strides[4 * i + 2]; t.sw[i] = strides[4 * i + 3];
+    t.O[i] = O[i]; t.I[i] = I[i]; t.KS[i] = k[i];
+    t.first_block[i] = blocks;
+    blocks += (O[i] + 63) / 64 * 64;
+  }
+  t.first_block[n] = blocks;
+  t.count = n;
+  hipLaunchKernelGGL(k_prep_weights_fp8_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }

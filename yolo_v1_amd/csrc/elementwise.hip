@@ -154,6 +154,8 @@ struct ApplyArgs {
   const float* rscale; const float* rshift;   // when set, residual is a raw conv output with its own BN
   long long npix; int C; int relu;
   unsigned char* relu_mask;       // optional [npix][C/8]: bit k of byte j = output channel 8j+k is > 0
+  unsigned char* z8 = nullptr;    // optional second output: e4m3 of the bf16 result (operand of the next fp8 convolution)
+  int ldz8 = 0;
 };
 
 __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
@@ -191,7 +193,16 @@ __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
     }
-    *reinterpret_cast<u32x4*>(a.z + pix * a.ldz + cc) = pack8(f);
+    const u32x4 zb = pack8(f);
+    *reinterpret_cast<u32x4*>(a.z + pix * a.ldz + cc) = zb;
+    if (a.z8) {                              // quantise the STORED (bf16-rounded) values, as the fp8 inference path does
+      float r[8];
+      unpack8(zb, r);
+      uint2 o;
+      o.x = pack_e4m3x4(r[0], r[1], r[2], r[3]);
+      o.y = pack_e4m3x4(r[4], r[5], r[6], r[7]);
+      *reinterpret_cast<uint2*>(a.z8 + pix * a.ldz8 + cc) = o;
+    }
   }
 }
 
@@ -750,18 +761,34 @@ extern "C" int yv1_bn_eval_coeffs(int C, const float* gamma, const float* beta, 
   return YV1_OK;
 }
 
-extern "C" int yv1_bn_apply(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
-                            const float* shift, const float* res_scale, const float* res_shift, long long npix, int C,
-                            int relu, void* relu_mask, hipStream_t stream) {
+static int bn_apply_launch(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
+                           const float* shift, const float* res_scale, const float* res_shift, long long npix, int C,
+                           int relu, void* relu_mask, void* z8, int ldz8, hipStream_t stream) {
   if (!y || !z || !scale || !shift || npix <= 0 || C <= 0) return YV1_ERR_BAD_ARG;
-  if (C % 8 || ldy % 8 || ldz % 8 || (residual && ldr % 8)) return YV1_ERR_UNSUPPORTED;
+  if (C % 8 || ldy % 8 || ldz % 8 || (residual && ldr % 8) || (z8 && ldz8 % 8)) return YV1_ERR_UNSUPPORTED;
   ApplyArgs a;
   a.y = (const bf16_t*)y; a.ldy = ldy; a.z = (bf16_t*)z; a.ldz = ldz; a.res = (const bf16_t*)residual; a.ldr = ldr;
   a.scale = scale; a.shift = shift; a.rscale = res_scale; a.rshift = res_shift; a.npix = npix; a.C = C; a.relu = relu;
-  a.relu_mask = (unsigned char*)relu_mask;
+  a.relu_mask = (unsigned char*)relu_mask; a.z8 = (unsigned char*)z8; a.ldz8 = ldz8;
   hipLaunchKernelGGL(k_bn_apply, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
+}
+
+extern "C" int yv1_bn_apply(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
+                            const float* shift, const float* res_scale, const float* res_shift, long long npix, int C,
+                            int relu, void* relu_mask, hipStream_t stream) {
+  return bn_apply_launch(y, ldy, z, ldz, residual, ldr, scale, shift, res_scale, res_shift, npix, C, relu, relu_mask, nullptr,
+                         0, stream);
+}
+
+// yv1_bn_apply with a second, e4m3 copy of the result (pixel stride ldz8 bytes): the operand of the next fp8 convolution
+extern "C" int yv1_bn_apply_q8(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, const float* scale,
+                               const float* shift, const float* res_scale, const float* res_shift, long long npix, int C,
+                               int relu, void* relu_mask, void* z8, int ldz8, hipStream_t stream) {
+  if (!z8) return YV1_ERR_BAD_ARG;
+  return bn_apply_launch(y, ldy, z, ldz, residual, ldr, scale, shift, res_scale, res_shift, npix, C, relu, relu_mask, z8,
+                         ldz8, stream);
 }
 
 // pixels per workgroup of the column-parallel reductions: aim for ~2048 workgroups (8 per CU) so small

@@ -80,6 +80,10 @@ class HipBackbone(nn.Module):
         self._phase_boundary = None
         self.wgrad_side_stream = os.environ.get("YV1_WGRAD_SIDE_STREAM", "1") != "0"
         self.fused_eval = os.environ.get("YV1_FUSED_EVAL", "1") != "0"   # eval(): BatchNorm folded into the conv epilogue
+        # training: run the forward convolutions on the fp8 (e4m3) MFMA path -- "fp8 forward GEMMs, bf16 backward"
+        # (BASELINE config 5); off by default: the headline configuration computes in bf16
+        self.fp8_forward = os.environ.get("YV1_FP8_FORWARD", "0") == "1"
+        self._convw8 = {}     # ConvParam -> ops.Fp8Weights
 
     def set_grad_ready_hook(self, fn):
         """``fn([(param, grad), ...])`` is called from inside the backward executor as soon as the
@@ -105,6 +109,18 @@ class HipBackbone(nn.Module):
             self._convw[conv] = w
         w.refresh()
         return w
+
+    def cw8(self, conv):
+        w = self._convw8.get(conv)
+        if w is None or w.param is not conv.weight:
+            w = ops.Fp8Weights(conv.weight, conv.kernel_size, conv.stride, conv.padding)
+            self._convw8[conv] = w
+        return w
+
+    def refresh_all_weights_fp8(self):
+        """e4m3 shadows of every convolution with Cin % 64 == 0 (the stem and DenseNet's odd widths stay bf16)."""
+        ws = [self.cw8(m) for m in self.modules() if isinstance(m, ConvParam) and m.in_channels % 64 == 0]
+        ops.refresh_many_fp8(ws)
 
     def refresh_all_weights(self):
         """bf16 shadow copies of every convolution weight, refreshed in one multi-tensor launch."""

@@ -165,6 +165,95 @@ def stem_fwd_bn_act(xp, w, y, H, W, st, relu=True):
                                                 1 if relu else 0, stream_ptr(dev)), "yv1_conv2d_stem_fwd_bn_act_bf16")
 
 
+# ------------------------------------------------------------------ fp8 forward GEMMs (training, BASELINE config 5)
+class Fp8Act:
+    """NHWC e4m3 activation [N,H,W,C] held as uint8 (scale 1)."""
+    __slots__ = ("t", "N", "H", "W", "C", "ld", "p")
+
+    def __init__(self, N, H, W, C, device):
+        self.t = torch.empty((N, H, W, C), dtype=torch.uint8, device=device)
+        self.N, self.H, self.W, self.C, self.ld = N, H, W, C, C
+        self.p = self.t.data_ptr()
+
+
+class Fp8Weights:
+    """e4m3 shadow of one conv weight for the forward GEMM: [Opad][taps][I] bytes + alpha = 1/q per output channel
+    (q: the power of two each output channel is scaled by before rounding).  Refreshed with the bf16 shadows."""
+
+    def __init__(self, param, k, stride, pad):
+        self.param = param
+        self.O, self.I = param.shape[0], param.shape[1]
+        self.k, self.stride, self.pad = k, stride, pad
+        self.Opad = (self.O + 63) // 64 * 64
+        self.version = -1
+        self.w8 = self.alpha = None
+
+
+_ZERO_BETA = {}
+
+
+def _zero_beta(n, device):
+    key = (torch.device(device).index, n)
+    if key not in _ZERO_BETA:
+        _ZERO_BETA[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return _ZERO_BETA[key]
+
+
+def refresh_many_fp8(weights):
+    """Re-quantises every stale Fp8Weights (multi-tensor launches of yv1_prep_weights_fp8_multi)."""
+    import ctypes
+    stale = []
+    for w in weights:
+        p = w.param
+        ver = (p._version, _WEIGHT_EPOCH[0])
+        if w.w8 is not None and ver == w.version and w.w8.device == p.device:
+            continue
+        if w.w8 is None or w.w8.device != p.device:
+            w.w8 = torch.empty((w.Opad, w.k * w.k, w.I), dtype=torch.uint8, device=p.device)
+            w.alpha = torch.empty(w.Opad, dtype=torch.float32, device=p.device)
+        stale.append((w, ver))
+    if not stale:
+        return
+    L = lib()
+    maxn = L.yv1_prep_weights_fp8_max_tensors()
+    dev = stale[0][0].param.device
+    for i in range(0, len(stale), maxn):
+        chunk = [w for w, _ in stale[i:i + maxn]]
+        n = len(chunk)
+        PA, IA, LA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * (4 * n)
+        strides = []
+        for w in chunk:
+            strides.extend(w.param.stride())
+        check(L.yv1_prep_weights_fp8_multi(PA(*[w.param.data_ptr() for w in chunk]), LA(*strides), IA(*[w.O for w in chunk]),
+                                           IA(*[w.I for w in chunk]), IA(*[w.k for w in chunk]),
+                                           PA(*[w.w8.data_ptr() for w in chunk]), PA(*[w.alpha.data_ptr() for w in chunk]), n,
+                                           stream_ptr(dev)), "yv1_prep_weights_fp8_multi")
+    for w, ver in stale:
+        w.version = ver
+
+
+def quantize_fp8(x, out=None):
+    """bf16 Act -> e4m3 Fp8Act (saturating at +-448)."""
+    dev = x.t.device
+    out = out or Fp8Act(x.N, x.H, x.W, x.C, dev)
+    check(lib().yv1_quantize_bf16_to_fp8(x.p, x.ld, out.p, out.ld, x.npix, x.C, stream_ptr(dev)), "yv1_quantize_bf16_to_fp8")
+    return out
+
+
+def conv_fwd_fp8(x8, w8, y, want_stats=True):
+    """y (bf16 Act) = conv(x8, w8) on the fp8 MFMA, dequantised; returns the BN-statistic partials like conv_fwd."""
+    dev = x8.t.device
+    L = lib()
+    stats = None
+    if want_stats:
+        rows = L.yv1_conv2d_fp8_stats_rows(y.npix, w8.Opad)
+        stats = _f32(rows * 2 * w8.Opad, dev).view(rows, 2, w8.Opad)
+    check(L.yv1_conv2d_fwd_stats_nhwc_fp8(x8.p, ptr(w8.w8), ptr(w8.alpha), ptr(_zero_beta(w8.Opad, dev)), y.p, y.ld, ptr(stats),
+                                          x8.N, x8.H, x8.W, x8.ld, w8.I, w8.Opad, w8.k, w8.stride, w8.pad, stream_ptr(dev)),
+          "yv1_conv2d_fwd_stats_nhwc_fp8")
+    return stats
+
+
 def pack_input(images):
     """NCHW fp32 -> zero-padded NHWC4 bf16 [N][H+6][W+6][4]."""
     N, C, H, W = images.shape
@@ -376,14 +465,20 @@ class ReluMask:
         self.ld = C // 8
 
 
-def bn_apply(y, st, z, relu=True, residual=None, res_state=None, want_mask=False):
+def bn_apply(y, st, z, relu=True, residual=None, res_state=None, want_mask=False, z8=None):
+    """z = relu?(scale*y + shift [+ residual | + BN'd projection]); ``z8`` (Fp8Act): an e4m3 copy of z written by the same
+    launch (operand of the next fp8 convolution)."""
     dev = y.t.device
     mask = ReluMask(y.npix, y.C, dev) if (want_mask and relu) else None
-    check(lib().yv1_bn_apply(y.p, y.ld, z.p, z.ld, residual.p if residual is not None else None,
-                             residual.ld if residual is not None else 0, ptr(st.scale), ptr(st.shift),
-                             ptr(res_state.scale) if res_state is not None else None,
-                             ptr(res_state.shift) if res_state is not None else None, y.npix, y.C, 1 if relu else 0,
-                             mask.p if mask is not None else None, stream_ptr(dev)), "yv1_bn_apply")
+    args = (y.p, y.ld, z.p, z.ld, residual.p if residual is not None else None,
+            residual.ld if residual is not None else 0, ptr(st.scale), ptr(st.shift),
+            ptr(res_state.scale) if res_state is not None else None,
+            ptr(res_state.shift) if res_state is not None else None, y.npix, y.C, 1 if relu else 0,
+            mask.p if mask is not None else None)
+    if z8 is None:
+        check(lib().yv1_bn_apply(*args, stream_ptr(dev)), "yv1_bn_apply")
+    else:
+        check(lib().yv1_bn_apply_q8(*args, z8.p, z8.ld, stream_ptr(dev)), "yv1_bn_apply_q8")
     return mask
 
 

@@ -214,6 +214,7 @@ def main(argv=None):
     ap.add_argument("--pretrained", default=None, help="ImageNet state_dict file (torchvision keys) for the by-name "
                                                        "initialisation of train.py:59-78; no network access here")
     ap.add_argument("--resume", default=None, help="checkpoint written by this script or by the reference")
+    ap.add_argument("--fp8-forward", action="store_true", help="ResNet: forward convolutions on the fp8 (e4m3) MFMA path")
     ap.add_argument("--loader", action="store_true",
                     help="feed every step from a DataLoader (synthetic yoloDataset, 4 workers as train.py:119) through "
                          "the device prefetcher + device target encoder instead of one resident batch")
@@ -228,6 +229,8 @@ def main(argv=None):
     logger = create_logger(base, 'train') if rank == 0 else None
     net, loss_layer, opt = build(args.backbone, args.S, DEFAULTS["B"], DEFAULTS["clsN"], bs, device, logger=logger,
                                  quiet=rank != 0)
+    if args.fp8_forward:
+        net.fp8_forward = True
     if args.pretrained or args.resume:
         from . import checkpoint
         if args.pretrained:
