@@ -150,6 +150,7 @@ def main():
         gflop = TRAIN_GFLOP_PER_IMG[(args.backbone, args.S)]
         step_s_dev = dev_ms / 1e3 / args.steps
         achieved = args.batch * gflop / 1e3 / step_s_dev          # TFLOP/s on one GPU, device time of the step
+        traffic = measured_traffic(args.backbone, args.S, args.batch) if not args.fp8_forward else None
         out = {
             "metric": "images/sec training (ResNet-50 448^2, S=7)" if args.backbone == "resnet" and args.S == 7
             else "images/sec training (%s 448^2, S=%d)" % (args.backbone, args.S),
@@ -165,7 +166,10 @@ def main():
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager launches"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": measured_traffic(args.backbone, args.S, args.batch),
+                         "traffic": traffic,
+                         # informative: the same step against the HBM roofline (PMC bytes / device time, 8 TB/s peak)
+                         "hbm_GBps": round(traffic / step_s_dev / 1e9, 1) if traffic else None,
+                         "hbm_frac": round(traffic / step_s_dev / 8e12, 4) if traffic else None,
                          "note": "whole training step of one GPU: %.2f algorithmic conv GFLOP/img x %d img / %.3f ms "
                                  "(HIP-event time of the step on the launch stream)" % (gflop, args.batch, step_s_dev * 1e3)},
             "final_loss": round(final_loss, 5),
