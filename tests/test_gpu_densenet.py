@@ -84,6 +84,11 @@ def test_densenet121_eval_mode_and_train_steps():
         a = net(x.to(DEV)).cpu()
         ref = ob.densenet121_forward(x, P, S, training=False, q=ob.bf16_ste)
     assert (a - ref).abs().max().item() <= 3e-2
+    with torch.no_grad():                                # norm2 + ReLU in the conv epilogue vs the separate BN-apply pass
+        net.fused_eval = False
+        b = net(x.to(DEV)).cpu()
+        net.fused_eval = True
+    assert (a - b).abs().max().item() <= 2e-2 and (b - ref).abs().max().item() <= 3e-2
     net.train()
     images, target = synthetic_batch(8, 4, hw=128, device=DEV)
     opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)

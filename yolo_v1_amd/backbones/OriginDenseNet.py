@@ -128,10 +128,16 @@ class DenseNet(HipBackbone):
                     st1 = norm(table, buf.npix, layer.norm1, cin)
                     t1 = ops.new_act(N, h, w, cin, dev)
                     ops.bn_apply(xin, st1, t1, relu=True)
-                    y1 = ops.new_act(N, h, w, w1.Opad, dev)
-                    st2 = norm(ops.conv_fwd(t1, w1, y1, train), y1.npix, layer.norm2)
                     t2 = ops.new_act(N, h, w, w1.Opad, dev)
-                    ops.bn_apply(y1, st2, t2, relu=True)
+                    if not train and self.fused_eval:
+                        # eval(): norm2 + ReLU ride in the 1x1 convolution's epilogue (norm1 acts on the concat input
+                        # and stays a separate pass)
+                        y1 = st2 = None
+                        ops.conv_fwd_bn_act(t1, w1, t2, ops.bn_eval_state(layer.norm2), relu=True)
+                    else:
+                        y1 = ops.new_act(N, h, w, w1.Opad, dev)
+                        st2 = norm(ops.conv_fwd(t1, w1, y1, train), y1.npix, layer.norm2)
+                        ops.bn_apply(y1, st2, t2, relu=True)
                     stats = ops.conv_fwd(t2, w2, buf.window(cin, self.growth), train)
                     if train:
                         ops.stats_merge(stats, table[0], cin)
