@@ -16,15 +16,19 @@
 // 32 contiguous elements over a zero-padded NHWC4 image (see yv1_pack_input_nhwc4).
 //
 // Tiling (wave64, v_mfma_f32_32x32x16_bf16): 256 threads = 4 wavefronts per workgroup, each wave
-// owns a (BM/WM)x(BN/WN) sub-tile as 32x32 accumulator blocks; A/B tiles are register-staged
-// (global_load_dwordx4 issued one K-step ahead, ds_write_b128 after the MFMA block) into a
-// double-buffered LDS image whose 16-B chunks are XOR-swizzled so every ds_read_b128 fragment
-// read is bank-conflict-free; one barrier per K-step.
+// owns a (BM/WM)x(BN/WN) sub-tile as 32x32 accumulator blocks; the LDS image of a tile has its 16-B
+// chunks XOR-swizzled so every ds_read_b128 fragment read is bank-conflict-free; one barrier per K-step.
+// Two main loops share everything else (tiles, swizzle, epilogue):
+//   k_conv_dma  (default) tiles travel global -> LDS by LDS-DMA into a ring of 2-3 stages, the next K-steps stay in
+//               flight across a raw s_barrier (counted s_waitcnt vmcnt) -- see the comment above the kernel;
+//   k_conv_gemm register-staged (global_load_dwordx4 one K-step ahead, ds_write_b128 after the MFMA block),
+//               double-buffered: the stem, 32-wide Cout tiles with Cin % 64 != 0, and YV1_CONV_DMA=0.
 // Epilogue: per-channel sum / sum-of-squares of the fp32 accumulators (training-mode BatchNorm
 // statistics, nn.BatchNorm2d at OriginResNet.py:123 etc.) reduced in-register + one shuffle and
 // written as per-M-tile partials (deterministic, no atomics); the tile is packed to bf16 through
 // LDS and stored as full 16-B channel runs (optionally accumulating into the destination, used by
-// the strided 1x1 shortcut dgrad).
+// the strided 1x1 shortcut dgrad, adding the ReLU-masked shortcut gradient, or -- inference -- applying the
+// folded eval-mode BatchNorm, the residual add and the ReLU).
 // Workgroup -> tile map is XCD-aware: the workgroups that share an XCD (blockIdx % 8) walk the
 // Cout tiles of the same pixel tile back to back, so the gathered A rows are re-read from that
 // XCD's L2, not from HBM.

@@ -16,6 +16,9 @@
 // atomics (which run at ~1/5 of the store rate on this chip).
 // The result layout [Cout][taps][Cin] fp32 is exactly the channels_last storage of the OIHW
 // parameter's .grad, so the optimizer consumes it without a layout pass.
+// Kernels: k_wgrad (generic, one tap per workgroup, register-staged), k_wgrad_dma (1x1 layers: LDS-DMA ring,
+// unpadded rows with XOR-swizzled 32-B segments), k_wgrad3x3 (3x3 stride 1: all nine taps per workgroup over an X
+// halo tile), k_wgrad_stem (7x7/2 stem: all seven filter rows per workgroup), k_reduce_slabs.
 #include "common.h"
 #include <stdlib.h>
 
