@@ -220,9 +220,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(WgradArgs a) {
 // ---- LDS-DMA ring form of k_wgrad (square 64x64 / 128x128 tiles, full channel tiles) --------------------------
 // Same GEMM, same transposed fragment reads, but the pixel-major tiles travel global -> LDS directly
 // (global_load_lds_dwordx4) into a ring of three stages with the next two K-steps in flight across a raw barrier,
-// like conv.hip's k_conv_dma.  A DMA instruction writes 1 KB of consecutive LDS, so the rows cannot be padded: the
-// four pixel rows of a transposed read are kept on disjoint bank quarters by XOR-ing the 32-byte segment index of a
-// row with (row & 3) -- on the source side (which 16-B chunk a lane fetches) and in the fragment-read address.
+// like conv.hip's k_conv_dma.  A DMA instruction writes 1 KB of consecutive LDS, so the rows cannot be padded.  A
+// 32-lane group of a transposed read touches 4 pixel rows x 2 adjacent 32-byte segments; unpadded rows alias on the
+// 256-byte bank row, so the byte offset inside a row is XOR-ed with (row & 3) << SEGSH -- 64-byte granularity for the
+// 256-byte rows of the 128-wide tile (8 distinct segments), 32-byte for the 128-byte rows of the 64-wide tile (whose
+// odd rows already sit on the other half of the bank row) -- on the source side (which 16-B chunk a lane fetches) and
+// in the fragment-read address.  PMC: SQ_LDS_BANK_CONFLICT 0 % of SQ_LDS_IDX_ACTIVE (50 % with a 32-byte XOR on the
+// 256-byte rows).
 __device__ __attribute__((aligned(16))) unsigned g_wg_zero_page[4];
 
 template <int NW>
@@ -241,6 +245,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
   constexpr int LPS = 2 * PPW;
   constexpr int A_BYTES = KP * ROWB, STAGE = 2 * A_BYTES;
   constexpr int TM = BT / 64, TN = BT / 64;
+  constexpr int SEGSH = BT == 128 ? 6 : 5;             // log2 of the XOR granularity in bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
 
   // DMA lane geometry: row (lane / CHR) of the piece, physical chunk lane % CHR holds logical chunk lchunk
   const int lrow = lane / CHR;
-  const int lchunk = (lane % CHR) ^ ((lrow & 3) << 1);
+  const int lchunk = (lane % CHR) ^ ((lrow & 3) << (SEGSH - 4));
   const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_wg_zero_page);
   const int PQ = a.P * a.Q;
   int xn[PPW], xp[PPW], xq[PPW];
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
   const int tq = li >> 2, tp = li & 3;
   const int h = g >> 1;
   const int chan_off = 16 * (g & 1) + 4 * tp;
-  const int xr = tq << 5;                              // (pixel row & 3) << 5: the row's segment XOR, in bytes
+  const int xr = tq << SEGSH;                          // (pixel row & 3) << SEGSH: the row's XOR, in bytes
 
   if (nsteps > 0) YV1_WGD_ISSUE(0);
   if (nsteps > 1) YV1_WGD_ISSUE(1);
