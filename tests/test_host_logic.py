@@ -158,3 +158,34 @@ def test_collate_raw_pads_boxes_to_batch_max():
     assert tuple(imgs.shape) == (3, 3, 32, 32) and tuple(boxes.shape) == (3, 3, 4) and tuple(labels.shape) == (3, 3)
     assert counts.tolist() == [3, 3, 0] and counts.dtype == torch.int32 and labels.dtype == torch.int64
     assert torch.equal(boxes[1], ds[1][1]) and float(boxes[2].abs().sum()) == 0.0
+
+
+def test_list_file_dataset_with_pil_loader(tmp_path):
+    """Darknet-style list file (utils/YOLODataLoader.py:94-106): image decoded + resized + normalised by the PIL loader,
+    labels read from the sibling ``labels`` directory and encoded."""
+    from PIL import Image
+    from yolo_v1_amd.utils.YOLODataLoader import collate_raw, encode_boxes, pil_image_loader, yoloDataset
+    (tmp_path / "JPEGImages").mkdir()
+    (tmp_path / "labels").mkdir()
+    rng = np.random.default_rng(0)
+    lines = []
+    for i, (w, h) in enumerate([(500, 375), (320, 480)]):
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(tmp_path / "JPEGImages" / ("%06d.jpg" % i))
+        (tmp_path / "labels" / ("%06d.txt" % i)).write_text("11 0.5 0.4 0.3 0.2\n3 0.1 0.9 0.05 0.1\n" if i == 0 else "7 0.7 0.2 0.5 0.3\n")
+        lines.append(str(tmp_path / "JPEGImages" / ("%06d.jpg" % i)))
+    lst = tmp_path / "train.txt"
+    lst.write_text("\n".join(lines) + "\n")
+    ds = yoloDataset(str(lst), train=False, with_file_path=True, S=7)
+    img, tgt, fname = ds[0]
+    assert tuple(img.shape) == (3, 448, 448) and img.dtype == torch.float32 and fname == lines[0]
+    assert -2.2 < float(img.min()) and float(img.max()) < 2.7            # (x - mean) / std of values in [0, 1]
+    want = encode_boxes(torch.tensor([[0.5, 0.4, 0.3, 0.2], [0.1, 0.9, 0.05, 0.1]]), torch.tensor([11, 3]), 7)
+    assert torch.equal(tgt, want)
+    # BGR order like cv2.imread: channel 0 of the tensor is the file's blue channel
+    rgb = pil_image_loader(lines[0], bgr=False)
+    b0 = (img[0] * 0.229 + 0.485)
+    r2 = (rgb[2] * 0.225 + 0.406)
+    assert torch.allclose(b0, r2, atol=1e-5)
+    raw = yoloDataset(str(lst), train=False, S=7, raw_targets=True)
+    imgs, boxes, labels, counts = collate_raw([raw[0], raw[1]])
+    assert counts.tolist() == [2, 1] and labels[1, 0].item() == 7 and tuple(imgs.shape) == (2, 3, 448, 448)

@@ -215,6 +215,8 @@ def main(argv=None):
                                                        "initialisation of train.py:59-78; no network access here")
     ap.add_argument("--resume", default=None, help="checkpoint written by this script or by the reference")
     ap.add_argument("--fp8-forward", action="store_true", help="ResNet: forward convolutions on the fp8 (e4m3) MFMA path")
+    ap.add_argument("--list-file", default=None, help="darknet-style image list (labels next to the images, as the reference's "
+                                                     "datasets/train.txt); implies --loader; images are decoded by PIL")
     ap.add_argument("--loader", action="store_true",
                     help="feed every step from a DataLoader (synthetic yoloDataset, 4 workers as train.py:119) through "
                          "the device prefetcher + device target encoder instead of one resident batch")
@@ -242,11 +244,13 @@ def main(argv=None):
     sync = ydist.GradSync(net) if world > 1 else None
     images, target = synthetic_batch(bs, args.S, seed=1234 + rank, device=device)
     feed = None
-    if args.loader:
+    if args.loader or args.list_file:
         from torch.utils.data import DataLoader
         from .utils.YOLODataLoader import DevicePrefetcher, collate_raw, yoloDataset
-        ds = yoloDataset(None, S=args.S, B=DEFAULTS["B"], C=DEFAULTS["clsN"], raw_targets=True, seed=1234 + rank,
+        ds = yoloDataset(args.list_file, S=args.S, B=DEFAULTS["B"], C=DEFAULTS["clsN"], raw_targets=True, seed=1234 + rank,
                          length=bs * args.iters_per_epoch)
+        if args.list_file:
+            args.iters_per_epoch = max(1, len(ds) // bs)
         feed = DevicePrefetcher(DataLoader(ds, batch_size=bs, shuffle=True, num_workers=4, collate_fn=collate_raw,
                                            drop_last=True), device, args.S, DEFAULTS["B"], DEFAULTS["clsN"])
     lr, it = DEFAULTS["learning_rate"], 0

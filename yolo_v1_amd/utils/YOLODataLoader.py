@@ -7,9 +7,9 @@
     ``randn(3,448,448)``, ``objs`` boxes with cx,cy~U(0,1), w,h~U(0.05,0.9), class~U{0..C-1}
     (SURVEY 8d); nothing is read from disk, so the throughput bench needs no dataset;
   * a darknet-style label list (``<img path>`` lines, labels next to the images as
-    ``cls cx cy w h`` rows, reference :94-106): boxes/labels are read and encoded; image decoding
-    and the imgaug pipeline (:31-79, :161-172) need cv2/imgaug and are out of scope here, so an
-    ``image_loader`` callable must be supplied for real images.
+    ``cls cx cy w h`` rows, reference :94-106): boxes/labels are read and encoded; images are decoded,
+    resized and normalised by ``pil_image_loader`` (or any ``image_loader`` callable); the imgaug
+    augmentation pipeline (:31-79, :161-172) needs cv2/imgaug and is out of scope here.
 ``encode_boxes`` is host code, as in the reference (it runs in DataLoader worker processes);
 ``encode_targets_device`` is the same encoder as one HIP kernel over a whole batch, and
 ``DevicePrefetcher`` feeds the training loop: pinned staging buffers, H2D copies and the device encoder on a
@@ -43,6 +43,27 @@ def encode_boxes(boxes, labels, S, B=2, C=20):
         cellv[B:B * 5] = torch.cat([delta[k], boxes[k, 2:]]).repeat(B)
         target[row, col] = cellv
     return target
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)      # train.py:108 (applied to the BGR channels cv2.imread returns, as the reference does)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def pil_image_loader(path, size=448, bgr=True):
+    """Image file -> normalised fp32 tensor [3,size,size]: what the reference's transform (train.py:105-109:
+    ``cv_resize`` -> ``ToTensor`` -> ``Normalize``) makes of ``cv2.imread(path)``, with PIL standing in for cv2 (bilinear
+    resize; not bit-identical to cv2's -- image decoding is outside the pinned path).  No augmentation."""
+    from PIL import Image
+    import numpy as np
+    with Image.open(path) as im:
+        im = im.convert("RGB").resize((size, size), Image.BILINEAR)
+        a = np.asarray(im, dtype=np.float32) / 255.0
+    if bgr:
+        a = a[:, :, ::-1]
+    t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+    mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+    return (t - mean) / std
 
 
 def collate_raw(samples):
@@ -227,10 +248,10 @@ class yoloDataset(data.Dataset):
             img, boxes, labels, fname = self._synthetic_item(idx)
         else:
             fname = self.fnames[idx]
-            if self.image_loader is None:
-                raise RuntimeError("yoloDataset: reading real images needs an image_loader callable "
-                                   "(cv2/imgaug are not part of this package)")
-            img = self.image_loader(fname)
+            loader = self.image_loader
+            if loader is None:          # default: PIL decode + resize + normalise (no cv2 / imgaug in this package)
+                loader = lambda f: pil_image_loader(f, self.image_size)
+            img = loader(fname)
             if self.transform is not None:
                 img = self.transform(img)
             boxes, labels = self.get_boxes_labels(fname)
