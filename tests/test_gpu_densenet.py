@@ -207,3 +207,43 @@ def test_mini_densenet_backward_tight():
         if not ok:
             bad.append((k, round(c, 4), round(ratio, 3)))
     assert not bad, bad
+
+
+def test_densenet_graphed_steps_single_and_data_parallel_are_bitwise_the_eager_step():
+    """hipGraph replay of the DenseNet training step (one rank: whole step in one graph; data-parallel form rehearsed with a
+    1-rank RCCL group: forward+backward graph, one collective, fused SGD) against the eager step, bit for bit."""
+    import torch.distributed as dist
+    from yolo_v1_amd.backbones.OriginDenseNet import densenet121
+    from yolo_v1_amd.distributed import GradSync
+    from yolo_v1_amd.optim import FusedSGD
+    from yolo_v1_amd.train import GraphedStep, train_step
+    from yolo_v1_amd.utils.YOLODataLoader import synthetic_batch
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    images, target = synthetic_batch(4, 4, hw=128, device=DEV)
+    lrs = [1e-3, 2e-3, 5e-4]
+    torch.manual_seed(0)
+    a = densenet121(S=14).to(DEV).train()
+    init = {k: v.clone() for k, v in a.state_dict().items()}
+    oa = FusedSGD(a.parameters(), lr=0.0, momentum=0.99)
+    ref = [train_step(a, YOLOLossV1(4, 4, 2, 20, _quiet=True), oa, images, target, lr).item() for lr in lrs]
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29519", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        for with_sync in (False, True):
+            b = densenet121(S=14).to(DEV).train()
+            b.load_state_dict(init)
+            ob_ = FusedSGD(b.parameters(), lr=0.0, momentum=0.99)
+            for grp in ob_.param_groups:
+                grp['lr'] = lrs[0]
+            gs = GraphedStep(b, YOLOLossV1(4, 4, 2, 20, _quiet=True), ob_, images, target, GradSync(b) if with_sync else None,
+                             warmup=1)
+            assert not gs.two_phase                      # no phase boundary in this executor: one graph, one collective
+            got = [gs(lr).item() for lr in lrs[1:]]
+            assert got == ref[1:], (with_sync, got, ref[1:])
+            pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+            for k in ("features.conv0.weight", "features.denseblock2.denselayer5.conv2.weight", "features.norm5.weight", "bn_end.bias"):
+                assert torch.equal(pa[k], pb[k]), (with_sync, k)
+    finally:
+        if created:
+            dist.destroy_process_group()
