@@ -60,6 +60,46 @@ def cpu_baseline(steps=60, warmup=3):
                       "oracle port of train.py:158-172" % (steps, warmup)}
 
 
+def host_input_rate(graphed, step, images, target, steps):
+    """The boundary of the reference hands over host tensors (DataLoader batches, train.py:119-127): the same steps
+    with every batch starting in pinned host memory.  Batch t+1 crosses PCIe on a copy stream while step t runs; the
+    launch stream waits on the copy's event and moves the batch into the graph's static input buffers."""
+    dev = images.device
+    host = [(images.cpu().pin_memory(), target.cpu().pin_memory()) for _ in range(2)]
+    stage = [(torch.empty_like(images), torch.empty_like(target)) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [torch.cuda.Event(), torch.cuda.Event()]
+    cur = torch.cuda.current_stream(dev)
+
+    def upload(slot):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[slot])            # the staging slot was drained by an earlier step
+            stage[slot][0].copy_(host[slot][0], non_blocking=True)
+            stage[slot][1].copy_(host[slot][1], non_blocking=True)
+            ready[slot].record(copy_stream)
+
+    for s_ in range(2):
+        consumed[s_].record(cur)
+    upload(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        slot = i & 1
+        upload(slot ^ 1)                                      # next batch, overlapped with this step
+        cur.wait_event(ready[slot])
+        graphed.images.copy_(stage[slot][0])
+        graphed.target.copy_(stage[slot][1])
+        consumed[slot].record(cur)
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mb = (images.numel() * images.element_size() + target.numel() * target.element_size()) / 1e6
+    return {"value": round(images.shape[0] * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
+            "h2d_MB_per_step": round(mb, 1), "note": "pinned host fp32 batch -> copy stream -> static graph inputs, "
+            "one batch ahead; PCIe-inclusive, informative only"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +109,9 @@ def main():
     ap.add_argument("--backbone", default="resnet", choices=["resnet", "densenet"])
     ap.add_argument("--S", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-input", type=int, default=1,
+                    help="after the timed region, also time the same steps fed from pinned host memory (fp32 batch per "
+                         "step over PCIe, copy stream, one batch ahead) and report it as host_input -- never as value")
     ap.add_argument("--fused-sgd", type=int, default=1)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     ap.add_argument("--fp8-forward", action="store_true",
@@ -174,6 +217,8 @@ def main():
                                  "(HIP-event time of the step on the launch stream)" % (gflop, args.batch, step_s_dev * 1e3)},
             "final_loss": round(final_loss, 5),
         }
+        if world == 1 and args.host_input and graphed is not None:
+            out["host_input"] = host_input_rate(graphed, step, images, target, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
