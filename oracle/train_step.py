@@ -85,9 +85,11 @@ def make_state(kind="resnet", S=7, seed=0):
 
 
 def train_steps(P, images, target, S, steps, kind="resnet", B=2, C=20, batch_size=None, lr0=0.0,
-                epoch=0, lr_map=None, start_iter=0, timings=None):
+                epoch=0, lr_map=None, start_iter=0, timings=None, fwd_kwargs=None, grid=None):
     """Runs ``steps`` iterations of train.py:155-172 on CPU.  Returns a list of
-    dicts {loss, comps[4], lr} per step."""
+    dicts {loss, comps[4], lr} per step.  ``fwd_kwargs`` reach the backbone restatement (e.g. the bf16-storage
+    emulation hook ``q=`` the GPU parity tests use); ``grid`` is the output grid when the images are not 448x448
+    (S then only selects the architecture variant, as in the backbone restatement)."""
     fwd = ob.resnet50_forward if kind == "resnet" else ob.densenet121_forward
     lr_map = lr_map or {}
     params = [v for v in P.values() if v.requires_grad]
@@ -100,8 +102,8 @@ def train_steps(P, images, target, S, steps, kind="resnet", B=2, C=20, batch_siz
         t0 = time.perf_counter()
         it += 1
         lr = learning_rate_policy(it, epoch, lr, lr_map)
-        pred = fwd(images, P, S, training=True)
-        total, comps = ol.yolo_loss(pred, target, S, B, C, 5.0, 0.5, bs)
+        pred = fwd(images, P, S, training=True, **(fwd_kwargs or {}))
+        total, comps = ol.yolo_loss(pred, target, grid or S, B, C, 5.0, 0.5, bs)
         opt.zero_grad()
         total.backward()
         opt.step(lr)

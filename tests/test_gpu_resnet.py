@@ -147,6 +147,68 @@ def test_train_loop_body_runs_and_loss_falls():
     assert losses[-1] < losses[0], losses
 
 
+def test_training_trajectory_follows_the_oracle_over_several_sgd_steps():
+    # train.py:155-172 repeated: the same weights, batch and learning-rate policy through the oracle (fp32 math, bf16
+    # storage hook) and through the product step (HIP backbone + loss kernel + fused SGD, momentum 0.99).  The loss
+    # sequence, the accumulated weight change and the BatchNorm running statistics must track each other.
+    # LR 1e-4 is the reference's second-phase rate (train.py lr map {75: 1e-4}).  Measured: losses within 0.5 %,
+    # weight-change cosine 0.91 (conv1) .. 0.99 (layer6), norm ratio 1.00 +- 0.006 after six steps; a single step
+    # already sits at cosine 0.93 for conv1 (ReLU-mask flips between two bf16 paths, see the module docstring).  At
+    # 1e-3 on these random weights the loss drops 25 -> 11 in six steps and the two bf16 trajectories, while keeping
+    # losses within 3 % and norms within 1 %, decorrelate in direction (conv1 cosine 0.64) -- chaos, not a defect, so
+    # the direction check is made where the problem is smooth.
+    from oracle import backbones as ob
+    from oracle import train_step as ots
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    from yolo_v1_amd.optim import FusedSGD
+    from yolo_v1_amd.train import learning_rate_policy, train_step
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    S, N, hw, steps = 7, 8, 256, 6
+    grid = hw // 64
+    P = ob.init_params(ob.resnet50_param_shapes(S), "resnet", seed=5)
+    for k in P:
+        if k.endswith("bn3.weight"):
+            P[k] = P[k] * 0.2                      # contractive regime, see the module docstring
+    P0 = {k: v.clone() for k, v in P.items()}
+    net = resnet50(S=S)
+    net.load_state_dict(P0, strict=True)
+    net = net.to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, 3, hw, hw, generator=g)
+    _, tg = ots.synthetic_batch(N, grid, hw=8)
+    lr_map = {0: 1e-4}
+
+    for k, v in P.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    ref = ots.train_steps(P, x, tg, S, steps, "resnet", batch_size=N, lr_map=lr_map, fwd_kwargs={"q": ob.bf16_ste},
+                          grid=grid)
+
+    opt = FusedSGD(net.parameters(), lr=0.0, momentum=0.99)
+    crit = YOLOLossV1(N, grid, 2, 20, _quiet=True)
+    xd, td = x.to(DEV), tg.to(DEV)
+    lr, got = 0.0, []
+    for it in range(1, steps + 1):
+        lr = learning_rate_policy(it, 0, lr, lr_map)
+        got.append(float(train_step(net, crit, opt, xd, td, lr).item()))
+    want = [r["loss"] for r in ref]
+    assert all(abs(r["lr"] - 1e-4) < 1e-12 for r in ref)
+    assert want[-1] < want[0]                       # the oracle's own trajectory descends ...
+    np.testing.assert_allclose(got, want, rtol=2e-2)  # ... and the HIP path follows it step by step
+    sd = net.state_dict()
+    for k in ("conv1.weight", "layer1.0.conv2.weight", "layer3.2.conv1.weight", "layer5.2.conv2.weight", "layer6.weight",
+              "layer4.1.bn2.weight", "bn_end.bias"):
+        d_ref = P[k].detach() - P0[k]
+        d_got = sd[k].detach().cpu().float() - P0[k]
+        c = _cos(d_got, d_ref)
+        ratio = float(d_got.norm() / (d_ref.norm() + 1e-30))
+        assert c >= (0.85 if d_ref.dim() == 4 else 0.8) and 0.9 <= ratio <= 1.1, "%s: cosine %.4f ratio %.3f" % (k, c, ratio)
+    np.testing.assert_allclose(sd["bn1.running_mean"].cpu().numpy(), P["bn1.running_mean"].numpy(), rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(sd["layer2.1.bn1.running_var"].cpu().numpy(), P["layer2.1.bn1.running_var"].numpy(),
+                               rtol=5e-2, atol=5e-3)
+    assert int(sd["layer3.2.bn2.num_batches_tracked"]) == steps
+
+
 def test_resnet50_every_layer_teacher_forced():
     """Each conv / BN+ReLU / block output of the HIP forward against fp32 torch math applied to the HIP
     path's own (bf16) input of that layer: isolates every kernel launch in the real network shapes."""
