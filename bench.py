@@ -60,6 +60,55 @@ def cpu_baseline(steps=60, warmup=3):
                       "oracle port of train.py:158-172" % (steps, warmup)}
 
 
+# (Cin, Cout, k, stride, Hin, count): the distinct Bottleneck convolutions of ResNet-50 at 448x448, S=7
+RESNET50_S7_CONVS = [(64, 64, 1, 1, 112, 1), (64, 64, 3, 1, 112, 3), (64, 256, 1, 1, 112, 4), (256, 64, 1, 1, 112, 2),
+                     (256, 128, 1, 1, 112, 1), (128, 128, 3, 2, 112, 1), (128, 512, 1, 1, 56, 4), (256, 512, 1, 2, 112, 1),
+                     (512, 128, 1, 1, 56, 3), (128, 128, 3, 1, 56, 3), (512, 256, 1, 1, 56, 1), (256, 256, 3, 2, 56, 1),
+                     (256, 1024, 1, 1, 28, 6), (512, 1024, 1, 2, 56, 1), (1024, 256, 1, 1, 28, 5), (256, 256, 3, 1, 28, 5),
+                     (1024, 512, 1, 1, 28, 1), (512, 512, 3, 2, 28, 1), (512, 2048, 1, 1, 14, 3), (1024, 2048, 1, 2, 28, 1),
+                     (2048, 512, 1, 1, 14, 3), (512, 512, 3, 1, 14, 2), (512, 512, 3, 2, 14, 1), (512, 2048, 1, 1, 7, 3),
+                     (2048, 2048, 1, 2, 14, 1), (2048, 512, 1, 1, 7, 2), (512, 512, 3, 1, 7, 2)]
+
+
+def conv_kernel_roofline(batch, device, iters=5):
+    """The dominant kernel family of the step -- the implicit-GEMM convolution (k_conv_dma: forward and data
+    gradient of the 58 Bottleneck convolutions) -- on its own: every distinct layer shape launched ``iters`` times
+    between HIP events on the launch stream, weighted by how often the step runs it.  Algorithmic flops / that time."""
+    from yolo_v1_amd import ops
+    flops = t_us = 0.0
+    per_launch = []
+    for ci, co, k, st, h, cnt in RESNET50_S7_CONVS:
+        pad = 1 if k == 3 else 0
+        oh = (h + 2 * pad - k) // st + 1
+        x = ops.Act(torch.randn(batch, h, h, ci, device=device).to(torch.bfloat16))
+        w = torch.nn.Parameter((torch.randn(co, ci, k, k, device=device) * 0.05).contiguous(memory_format=torch.channels_last))
+        cw = ops.ConvWeights(w, k, st, pad)
+        cw.refresh()
+        y = ops.new_act(batch, oh, oh, co, device)
+        dy = ops.Act(torch.randn(batch, oh, oh, co, device=device).to(torch.bfloat16))
+        dx = ops.new_act(batch, h, h, ci, device)
+        fl = 2.0 * batch * oh * oh * co * ci * k * k
+        for fn in (lambda: ops.conv_fwd(x, cw, y, True), lambda: ops.conv_dgrad(dy, cw, dx)):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / iters * 1e3
+            flops += cnt * fl
+            t_us += cnt * us
+            per_launch.append(us)
+    n = 2 * sum(c[5] for c in RESNET50_S7_CONVS)
+    tf = flops / t_us / 1e6
+    return {"name": "k_conv_dma: implicit-GEMM NHWC convolution, forward + data gradient of the Bottleneck convolutions",
+            "launches_per_step": n, "avg_launch_us": round(t_us / n, 1), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+            "note": "each distinct layer shape timed alone with HIP events (%d launches), weighted by its count in the "
+                    "step; inside the step the same launches share the chip with the weight-gradient stream" % iters}
+
+
 def host_input_rate(graphed, step, images, target, steps):
     """The boundary of the reference hands over host tensors (DataLoader batches, train.py:119-127): the same steps
     with every batch starting in pinned host memory.  Batch t+1 crosses PCIe on a copy stream while step t runs; the
@@ -219,6 +268,8 @@ def main():
         }
         if world == 1 and args.host_input and graphed is not None:
             out["host_input"] = host_input_rate(graphed, step, images, target, args.steps)
+        if world == 1 and args.backbone == "resnet" and args.S == 7 and not args.fp8_forward:
+            out["roofline"]["dominant_kernel"] = conv_kernel_roofline(args.batch, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
