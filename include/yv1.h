@@ -158,6 +158,18 @@ int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const voi
                      const float* invstd, const float* scale, const float* shift, const float* k1, const float* k2,
                      const float* k3, long long npix, int C, int mask_mode, void* dy, int lddy, void* dres, int lddres,
                      int accumulate, yv1_stream_t stream);
+/* BatchNorm(+ReLU) backward behind the stem's 3x3/2 max pool (OriginResNet.py:174-177, OriginDenseNet.py:120-128; autograd
+ * of nn.MaxPool2d + nn.ReLU + nn.BatchNorm2d): dpool [N,OH,OW,C] is the gradient of the pool OUTPUT, pool_idx what
+ * yv1_maxpool3x3s2_fwd stored; the pool's backward is gathered on the fly, so the 4x larger gradient of the pool input is
+ * never materialised.  y: BatchNorm input [N,H,W,C].  mask_mode 0 or 2.  Same results as yv1_maxpool3x3s2_bwd followed by
+ * yv1_bn_bwd_reduce / _apply, bit for bit. */
+int yv1_bn_bwd_reduce_pooled(const void* dpool, int lddp, const void* pool_idx, const void* y, int ldy, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, int N, int H, int W, int C,
+                             int mask_mode, float* partials, yv1_stream_t stream);
+int yv1_bn_bwd_apply_pooled(const void* dpool, int lddp, const void* pool_idx, const void* y, int ldy, const float* mean,
+                            const float* invstd, const float* scale, const float* shift, const float* k1, const float* k2,
+                            const float* k3, int N, int H, int W, int C, int mask_mode, void* dy, int lddy,
+                            yv1_stream_t stream);
 
 /* ---- pooling and head: OriginResNet.py:125,:188-189; OriginDenseNet.py:54,:80,:127-128 --------------------- */
 /* idx (nullable): uint8 [N,OH,OW,C] = window position of the first maximum (torch's tie rule), for the backward */

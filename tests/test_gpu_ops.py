@@ -249,6 +249,16 @@ def test_head_fwd_bwd():
     np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=1e-3, atol=1e-4)
 
 
+def _same_up_to_sum_order(dy_new, dy_ref, dg_new, dg_ref, db_new, db_ref):
+    """The per-channel sums agree to fp32 reordering; dy then differs by at most a bf16 rounding flip."""
+    for a_, b_ in ((dg_new, dg_ref), (db_new, db_ref)):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(b_.abs().max()))
+    a_, b_ = dy_new.t.float(), dy_ref.t.float()
+    diff = (a_ - b_).abs()
+    assert float((diff > 0).float().mean()) < 0.05, "more than 5 % of dy changed"
+    assert bool((diff <= b_.abs() * 2.0 ** -7 + 1e-6 * float(b_.abs().max())).all())
+
+
 def test_stem_chain_backward():
     """conv7x7/2 -> BN -> ReLU -> maxpool forward, then backward from a pooled-output gradient: the chain
     maxpool_bwd -> bn_backward(mask from scale*y+shift) -> stem wgrad on identical inputs."""
@@ -271,7 +281,7 @@ def test_stem_chain_backward():
     ops.bn_apply(y0, st, z0, relu=True)
     wide = ops.new_act(N, H // 4, Wd // 4, 128, DEV)          # pooled output lives in a channel window
     pooled = wide.window(0, 64)
-    ops.maxpool_fwd(z0, pooled)
+    pidx = ops.maxpool_fwd(z0, pooled, want_index=True)
     torch.cuda.synchronize()
     # reference from the HIP path's own bf16 tensors: y0 (raw conv out) is the BN input
     y0r = to_nchw(y0).requires_grad_(True)
@@ -292,6 +302,43 @@ def test_stem_chain_backward():
     close(to_nchw(dy0), y0r.grad, rtol=2e-2, scale_atol=2e-2)
     np.testing.assert_allclose(dg.cpu().numpy(), ref_bn.weight.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.weight.grad.abs().max()))
     np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=2e-2, atol=2e-2 * float(ref_bn.bias.grad.abs().max()))
+    # the training path: pool backward gathered inside the BatchNorm-backward kernels -- bit-identical to the chain above
+    dy0f = ops.new_act(N, H // 2, Wd // 2, 64, DEV)
+    dgf, dbf = ops.bn_backward(ga.window(0, 64), y0, st, bn, dy0f, 2, pool_idx=pidx)
+    torch.cuda.synchronize()
+    _same_up_to_sum_order(dy0f, dy0, dgf, dg, dbf, db)
+
+
+@pytest.mark.parametrize("N,H,Wd,C,mode", [(2, 15, 17, 64, 2), (1, 8, 8, 128, 0), (3, 31, 14, 64, 2), (64, 224, 224, 64, 2)])
+def test_bn_backward_behind_maxpool_equals_the_two_kernel_chain(N, H, Wd, C, mode):
+    """yv1_bn_bwd_{reduce,apply}_pooled == yv1_maxpool3x3s2_bwd + yv1_bn_bwd_{reduce,apply}, bit for bit: odd and even
+    map sizes (windows clipped at the borders), with and without the ReLU mask, and the full stem size."""
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(H * Wd + C)
+    y = ops.Act(bf(torch.randn(N, H, Wd, C, generator=g)).to(DEV).to(torch.bfloat16))
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data.uniform_(0.5, 1.5, generator=g)
+    bn.bias.data.uniform_(-0.3, 0.3, generator=g)
+    bn = bn.to(DEV)
+    st = ops.bn_finalize(ops.bn_stats(y), y.npix, bn)
+    z = ops.new_act(N, H, Wd, C, DEV)
+    ops.bn_apply(y, st, z, relu=mode == 2)
+    OH, OW = (H - 1) // 2 + 1, (Wd - 1) // 2 + 1
+    pooled = ops.new_act(N, OH, OW, C, DEV)
+    pidx = ops.maxpool_fwd(z, pooled, want_index=True)
+    gp = ops.Act(bf(torch.randn(N, OH, OW, C, generator=g)).to(DEV).to(torch.bfloat16))
+    dz = ops.new_act(N, H, Wd, C, DEV)
+    ops.maxpool_bwd(None, gp, dz, pidx)
+    dy_a, dy_b = ops.new_act(N, H, Wd, C, DEV), ops.new_act(N, H, Wd, C, DEV)
+    dg_a, db_a = ops.bn_backward(dz, y, st, bn, dy_a, mode)
+    dg_b, db_b = ops.bn_backward(gp, y, st, bn, dy_b, mode, pool_idx=pidx)
+    torch.cuda.synchronize()
+    if H % 2 or Wd % 2:                 # per-pixel gather: same summation order as the chain
+        assert torch.equal(dy_a.t, dy_b.t)
+        assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    else:                               # 2x2-patch kernels: identical gathered gradients, other fp32 summation order
+        _same_up_to_sum_order(dy_b, dy_a, dg_b, dg_a, db_b, db_a)
+    assert float(dy_a.t.float().abs().sum()) > 0
 
 
 @pytest.mark.parametrize("N,H,Wd,Cin,Cout", [(2, 16, 16, 256, 64), (3, 14, 14, 512, 128), (2, 7, 9, 2048, 512), (64, 28, 28, 256, 64)])

@@ -220,10 +220,9 @@ class DenseNet(HipBackbone):
 
         xp, y0, s0, z0, H, W, pidx = rec["stem"]
         w0 = self.cw(F.conv0, stem=True)
-        dz0 = ops.new_act(N, z0.H, z0.W, 64, dev)
-        ops.maxpool_bwd(z0, g_first, dz0, pidx)
+        # max-pool backward gathered inside the BatchNorm backward: the pool-input gradient is never materialised
         dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
-        grads[F.norm0.weight], grads[F.norm0.bias] = ops.bn_backward(dz0, y0, s0, F.norm0, dy0, 2)
+        grads[F.norm0.weight], grads[F.norm0.bias] = ops.bn_backward(g_first, y0, s0, F.norm0, dy0, 2, pool_idx=pidx)
         grads[F.conv0.weight] = ops.stem_wgrad(xp, dy0, w0, H, W, side)
         side.join()
         self._emit(grads, [F.norm0.weight, F.norm0.bias, F.conv0.weight])

@@ -256,10 +256,9 @@ class ResNet(HipBackbone):
 
         xp, y0, s0, z0, H, W, pidx = rec["stem"]
         w0 = self.cw(self.conv1, stem=True)
-        dz0 = ops.new_act(N, z0.H, z0.W, 64, dev)
-        ops.maxpool_bwd(z0, g, dz0, pidx)
+        # max-pool backward gathered inside the BatchNorm backward: the pool-input gradient is never materialised
         dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
-        grads[self.bn1.weight], grads[self.bn1.bias] = ops.bn_backward(dz0, y0, s0, self.bn1, dy0, 2)
+        grads[self.bn1.weight], grads[self.bn1.bias] = ops.bn_backward(g, y0, s0, self.bn1, dy0, 2, pool_idx=pidx)
         grads[self.conv1.weight] = ops.stem_wgrad(xp, dy0, w0, H, W, side)
         side.join()
         self._emit(grads, [self.bn1.weight, self.bn1.bias, self.conv1.weight])

@@ -278,10 +278,41 @@ struct BwdArgs {
   bf16_t* dy; int lddy;
   bf16_t* dres; int lddres;        // optional: masked dz copied out (identity shortcut gradient)
   int accumulate;                  // dy += result (DenseNet: several consumers of one feature map)
+  // pooled form (stem): dz is the gradient of a 3x3/2 max pool's OUTPUT [N,OH,OW,C]; pool_idx the pool's first-argmax
+  // codes; the pixel index p runs over the pool's INPUT [N,pH,pW], whose gradient is gathered on the fly
+  const unsigned char* pool_idx = nullptr; int pH = 0, pW = 0;
 };
 
+// gradient of the max pool's input pixel p, channels c8..c8+7: the (up to four) windows that contain the pixel hand
+// their gradient over when their stored argmax code names it (same arithmetic and summation order as k_maxpool_bwd_idx)
+__device__ __forceinline__ void pooled_grad(const BwdArgs& a, long long p, int c8, float* g) {
+  const unsigned H = a.pH, W = a.pW, up = (unsigned)p;
+  const unsigned w = up % W, t = up / W, h = t % H, n = t / H;
+  const int OH = (int)(H + 2 - 3) / 2 + 1, OW = (int)(W + 2 - 3) / 2 + 1;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) g[k] = 0.f;
+  const int oh_lo = h / 2, oh_hi = min(OH - 1, (int)(h + 1) / 2);
+  const int ow_lo = w / 2, ow_hi = min(OW - 1, (int)(w + 1) / 2);
+  for (int oh = oh_lo; oh <= oh_hi; ++oh)
+    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+      const unsigned code = (unsigned)(((int)h - (oh * 2 - 1)) * 3 + ((int)w - (ow * 2 - 1)));
+      const size_t o = (size_t)(n * OH + oh) * OW + ow;
+      const uint2 am2 = *reinterpret_cast<const uint2*>(a.pool_idx + o * a.C + c8);
+      float d[8];
+      unpack8(*reinterpret_cast<const u32x4*>(a.dz + o * a.lddz + c8), d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned am = ((k < 4 ? am2.x : am2.y) >> (8 * (k & 3))) & 0xffu;
+        g[k] += am == code ? d[k] : 0.f;
+      }
+    }
+  // the unfused path stores this gradient as bf16 before the BatchNorm backward reads it: round the same way
+  unpack8(pack8(g), g);
+}
+
 __device__ __forceinline__ void masked_grad(const BwdArgs& a, long long p, int c8, const float* yv, float* g) {
-  unpack8(*reinterpret_cast<const u32x4*>(a.dz + p * a.lddz + c8), g);
+  if (a.pool_idx) pooled_grad(a, p, c8, g);
+  else unpack8(*reinterpret_cast<const u32x4*>(a.dz + p * a.lddz + c8), g);
   if (a.mask_mode == 1) {
     float zv[8];
     unpack8(*reinterpret_cast<const u32x4*>(a.z + p * a.ldz + c8), zv);
@@ -399,6 +430,107 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
       for (int k = 0; k < 8; ++k) o[k] += old[k];
     }
     *reinterpret_cast<u32x4*>(a.dy + p * a.lddy + c8) = pack8(o);
+  }
+}
+
+// ---- pooled form on aligned 2x2 patches (even H and W: the stems) ------------------------------------------------
+// The per-pixel gather above re-reads every pool window for each of the up-to-nine pixels under it and pays two integer
+// divisions per pixel; it is latency-bound (the stem's pair ran no faster than max-pool backward + plain BN backward).
+// An aligned 2x2 patch of the pool input (rows 2a,2a+1 / columns 2b,2b+1) lies under exactly the four windows
+// (a,b) (a,b+1) (a+1,b) (a+1,b+1): one thread loads those four (index, gradient) pairs once and produces the four
+// pixel gradients, in the same summation order as k_maxpool_bwd_idx, rounded to bf16 like the tensor it replaces.
+__device__ __forceinline__ void pooled_patch_grad(const BwdArgs& a, unsigned n, unsigned pa, unsigned pb, int c8, int OH, int OW,
+                                                  float (&g)[4][8]) {
+  unsigned code[4][8];
+  float d[4][8];
+#pragma unroll
+  for (int wi = 0; wi < 4; ++wi) {
+    const unsigned oh = pa + (wi >> 1), ow = pb + (wi & 1);
+    const bool ok = (int)oh < OH && (int)ow < OW;
+    const size_t o = ok ? (size_t)(n * OH + oh) * OW + ow : 0;
+    const uint2 am2 = *reinterpret_cast<const uint2*>(a.pool_idx + o * a.C + c8);
+    unpack8(*reinterpret_cast<const u32x4*>(a.dz + o * a.lddz + c8), d[wi]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) code[wi][k] = ok ? ((k < 4 ? am2.x : am2.y) >> (8 * (k & 3))) & 0xffu : 0xffu;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    // window position r*3+s of pixel (h,w) inside window (oh,ow): r = h - (2oh-1), s = w - (2ow-1)
+    g[0][k] = 0.f + (code[0][k] == 4u ? d[0][k] : 0.f);
+    g[1][k] = (0.f + (code[0][k] == 5u ? d[0][k] : 0.f)) + (code[1][k] == 3u ? d[1][k] : 0.f);
+    g[2][k] = (0.f + (code[0][k] == 7u ? d[0][k] : 0.f)) + (code[2][k] == 1u ? d[2][k] : 0.f);
+    g[3][k] = (((0.f + (code[0][k] == 8u ? d[0][k] : 0.f)) + (code[1][k] == 6u ? d[1][k] : 0.f)) +
+               (code[2][k] == 2u ? d[2][k] : 0.f)) + (code[3][k] == 0u ? d[3][k] : 0.f);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) unpack8(pack8(g[q]), g[q]);
+}
+
+// reduce over patches: a.npix = number of patches, a.pix_per_block patches per block; C <= 8*TX (one column per thread)
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce_pool2(BwdArgs a, int TX) {
+  const int CH = a.C >> 3, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int OH = a.pH >> 1, OW = a.pW >> 1;
+  float acc[1][2][8];
+  float mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { acc[0][0][k] = 0.f; acc[0][1][k] = 0.f; mu[k] = 0.f; is[k] = 0.f; sc[k] = 0.f; sh[k] = 0.f; }
+  if (tx < CH) {
+    load8f(a.mean + tx * 8, mu); load8f(a.invstd + tx * 8, is);
+    if (a.mask_mode == 2) { load8f(a.scale + tx * 8, sc); load8f(a.shift + tx * 8, sh); }
+  }
+  const long long p0 = (long long)blockIdx.x * a.pix_per_block;
+  const long long p1 = min(a.npix, p0 + a.pix_per_block);
+  for (long long pp = p0 + ty; pp < p1; pp += TY) {
+    if (tx < CH) {
+      const unsigned up = (unsigned)pp;
+      const unsigned pb = up % OW, t = up / OW, pa = t % OH, n = t / OH;
+      float g[4][8];
+      pooled_patch_grad(a, n, pa, pb, tx * 8, OH, OW, g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t p = ((size_t)n * a.pH + 2 * pa + (q >> 1)) * a.pW + 2 * pb + (q & 1);
+        float yv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + tx * 8), yv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float gk = (a.mask_mode == 2 && !(yv[k] * sc[k] + sh[k] > 0.f)) ? 0.f : g[q][k];
+          acc[0][0][k] += gk;
+          acc[0][1][k] += gk * (yv[k] - mu[k]) * is[k];
+        }
+      }
+    }
+  }
+  block_column_reduce<2, 1>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_pool2(BwdArgs a) {
+  const int CH = a.C >> 3, OH = a.pH >> 1, OW = a.pW >> 1;
+  const long long total = a.npix * CH;                    // a.npix = number of patches
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const unsigned ui = (unsigned)i;
+    const int c8 = (int)(ui % CH) * 8;
+    unsigned t = ui / CH;
+    const unsigned pb = t % OW; t /= OW;
+    const unsigned pa = t % OH, n = t / OH;
+    float g[4][8];
+    pooled_patch_grad(a, n, pa, pb, c8, OH, OW, g);
+    float mu[8], is[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+    load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
+    load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+    if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t p = ((size_t)n * a.pH + 2 * pa + (q >> 1)) * a.pW + 2 * pb + (q & 1);
+      float yv[8], o[8];
+      unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8), yv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float gk = (a.mask_mode == 2 && !(yv[k] * sc[k] + sh[k] > 0.f)) ? 0.f : g[q][k];
+        o[k] = k1[k] * gk - k2[k] - (yv[k] - mu[k]) * is[k] * k3[k];
+      }
+      *reinterpret_cast<u32x4*>(a.dy + p * a.lddy + c8) = pack8(o);
+    }
   }
 }
 
@@ -834,10 +966,11 @@ extern "C" int yv1_bn_stats(const void* y, int ldy, long long npix, int C, float
   return YV1_OK;
 }
 
-extern "C" int yv1_bn_bwd_reduce(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
-                                 const float* invstd, const float* scale, const float* shift, long long npix, int C,
-                                 int mask_mode, float* partials, hipStream_t stream) {
+static int bn_bwd_reduce(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                         const float* invstd, const float* scale, const float* shift, long long npix, int C,
+                         int mask_mode, float* partials, const void* pool_idx, int pH, int pW, hipStream_t stream) {
   if (!dz || !y || !mean || !invstd || !partials || npix <= 0) return YV1_ERR_BAD_ARG;
+  if (pool_idx && (pH <= 0 || pW <= 0 || npix % ((long long)pH * pW) || npix >= (1ll << 31))) return YV1_ERR_BAD_ARG;
   if (((mask_mode == 1 || mask_mode == 3) && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
   int TX, ppb, blocks; size_t lds;
   int rc = reduce_geometry(npix, C, &TX, &ppb, &blocks, &lds);
@@ -847,10 +980,35 @@ extern "C" int yv1_bn_bwd_reduce(const void* dz, int lddz, const void* z, int ld
   a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
   a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.npix = npix; a.C = C; a.pix_per_block = ppb;
   a.mask_mode = mask_mode; a.part = partials;
+  a.pool_idx = (const unsigned char*)pool_idx; a.pH = pH; a.pW = pW;
+  if (pool_idx && pH % 2 == 0 && pW % 2 == 0 && C / 8 <= TX) {       // aligned 2x2 patches: same partial rows, patch ranges
+    a.npix = npix / 4;
+    a.pix_per_block = (int)((a.npix + blocks - 1) / blocks);
+    hipLaunchKernelGGL(k_bn_bwd_reduce_pool2, dim3(blocks), dim3(256), lds, stream, a, TX);
+    YV1_LAUNCH_CHECK();
+    return YV1_OK;
+  }
   if (C / 8 > TX) hipLaunchKernelGGL(k_bn_bwd_reduce<2>, dim3(blocks), dim3(256), lds, stream, a, TX);
   else hipLaunchKernelGGL(k_bn_bwd_reduce<1>, dim3(blocks), dim3(256), lds, stream, a, TX);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
+}
+
+extern "C" int yv1_bn_bwd_reduce(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, long long npix, int C,
+                                 int mask_mode, float* partials, hipStream_t stream) {
+  return bn_bwd_reduce(dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, npix, C, mask_mode, partials, nullptr, 0, 0, stream);
+}
+
+// BatchNorm(+ReLU) backward behind a 3x3/2 max pool (the stems, OriginResNet.py:174-177 / OriginDenseNet.py:120-128):
+// dpool [N,OH,OW,C] is the gradient of the POOL OUTPUT; the pool's backward is gathered on the fly from pool_idx, so the
+// gradient of the pool input ([N,H,W,C], 4x the bytes) is never written or re-read.  y is the BatchNorm input [N,H,W,C].
+extern "C" int yv1_bn_bwd_reduce_pooled(const void* dpool, int lddp, const void* pool_idx, const void* y, int ldy,
+                                        const float* mean, const float* invstd, const float* scale, const float* shift,
+                                        int N, int H, int W, int C, int mask_mode, float* partials, hipStream_t stream) {
+  if (!pool_idx || N <= 0 || (mask_mode != 0 && mask_mode != 2)) return YV1_ERR_BAD_ARG;
+  return bn_bwd_reduce(dpool, lddp, nullptr, 0, y, ldy, mean, invstd, scale, shift, (long long)N * H * W, C, mask_mode, partials,
+                       pool_idx, H, W, stream);
 }
 
 extern "C" int yv1_bn_bwd_finalize(const float* partials, int rows, int C, float count, const float* gamma,
@@ -871,11 +1029,12 @@ extern "C" int yv1_bn_bwd_finalize(const float* partials, int rows, int C, float
   return YV1_OK;
 }
 
-extern "C" int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
-                                const float* invstd, const float* scale, const float* shift, const float* k1,
-                                const float* k2, const float* k3, long long npix, int C, int mask_mode, void* dy, int lddy,
-                                void* dres, int lddres, int accumulate, hipStream_t stream) {
+static int bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                        const float* invstd, const float* scale, const float* shift, const float* k1,
+                        const float* k2, const float* k3, long long npix, int C, int mask_mode, void* dy, int lddy,
+                        void* dres, int lddres, int accumulate, const void* pool_idx, int pH, int pW, hipStream_t stream) {
   if (!dz || !y || !mean || !invstd || !k1 || !k2 || !k3 || !dy || npix <= 0) return YV1_ERR_BAD_ARG;
+  if (pool_idx && (pH <= 0 || pW <= 0 || npix % ((long long)pH * pW) || npix >= (1ll << 31))) return YV1_ERR_BAD_ARG;
   if (((mask_mode == 1 || mask_mode == 3) && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
   if (C % 8 || lddz % 8 || ldy % 8 || lddy % 8 || (z && mask_mode == 1 && ldz % 8) || (dres && lddres % 8)) return YV1_ERR_UNSUPPORTED;
   BwdArgs a = {};
@@ -883,9 +1042,33 @@ extern "C" int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz
   a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.npix = npix; a.C = C; a.mask_mode = mask_mode;
   a.k1 = k1; a.k2 = k2; a.k3 = k3; a.dy = (bf16_t*)dy; a.lddy = lddy; a.dres = (bf16_t*)dres; a.lddres = lddres;
   a.accumulate = accumulate;
+  a.pool_idx = (const unsigned char*)pool_idx; a.pH = pH; a.pW = pW;
+  if (pool_idx && pH % 2 == 0 && pW % 2 == 0) {
+    a.npix = npix / 4;
+    hipLaunchKernelGGL(k_bn_bwd_apply_pool2, dim3(ew_blocks(a.npix * (C / 8))), dim3(256), 0, stream, a);
+    YV1_LAUNCH_CHECK();
+    return YV1_OK;
+  }
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
+}
+
+extern "C" int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                                const float* invstd, const float* scale, const float* shift, const float* k1,
+                                const float* k2, const float* k3, long long npix, int C, int mask_mode, void* dy, int lddy,
+                                void* dres, int lddres, int accumulate, hipStream_t stream) {
+  return bn_bwd_apply(dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, k1, k2, k3, npix, C, mask_mode, dy, lddy, dres, lddres,
+                      accumulate, nullptr, 0, 0, stream);
+}
+
+extern "C" int yv1_bn_bwd_apply_pooled(const void* dpool, int lddp, const void* pool_idx, const void* y, int ldy,
+                                       const float* mean, const float* invstd, const float* scale, const float* shift,
+                                       const float* k1, const float* k2, const float* k3, int N, int H, int W, int C,
+                                       int mask_mode, void* dy, int lddy, hipStream_t stream) {
+  if (!pool_idx || N <= 0 || (mask_mode != 0 && mask_mode != 2)) return YV1_ERR_BAD_ARG;
+  return bn_bwd_apply(dpool, lddp, nullptr, 0, y, ldy, mean, invstd, scale, shift, k1, k2, k3, (long long)N * H * W, C, mask_mode,
+                      dy, lddy, nullptr, 0, 0, pool_idx, H, W, stream);
 }
 
 // idx (nullable): uint8 [N,OH,OW,C], window position (r*3+s) of the first maximum, consumed by the backward

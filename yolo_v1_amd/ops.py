@@ -482,11 +482,13 @@ def bn_apply(y, st, z, relu=True, residual=None, res_state=None, want_mask=False
     return mask
 
 
-def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=False):
+def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=False, pool_idx=None):
     """BN (+ReLU) backward.  mask_mode 0: no ReLU; 1: mask from ``z`` > 0; 2: mask from scale*y+shift > 0;
     3: ``z`` is the ReluMask bn_apply wrote.
     Writes dy (grad wrt the raw conv output) and optionally dres (masked dz, the identity-shortcut
-    gradient).  Returns (dgamma, dbeta)."""
+    gradient).  Returns (dgamma, dbeta).
+    With ``pool_idx`` (the index tensor of ``maxpool_fwd``) ``dz`` is the gradient of the 3x3/2 max pool that follows
+    the BN(+ReLU): the pool's backward is gathered inside both BatchNorm-backward kernels (stems)."""
     dev = y.t.device
     L = lib()
     C = y.C
@@ -494,13 +496,24 @@ def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=Fals
     part = _f32(rows * 2 * C, dev)
     s = stream_ptr(dev)
     zp, zld = (z.p, z.ld) if z is not None else (None, 0)
-    check(L.yv1_bn_bwd_reduce(dz.p, dz.ld, zp, zld, y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
-                              y.npix, C, mask_mode, ptr(part), s), "yv1_bn_bwd_reduce")
+    if pool_idx is not None:
+        if z is not None or dres is not None or accumulate:
+            raise ValueError("bn_backward: the pooled form takes mask_mode 0/2 only, no dres, no accumulate")
+        check(L.yv1_bn_bwd_reduce_pooled(dz.p, dz.ld, ptr(pool_idx), y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale),
+                                         ptr(st.shift), y.N, y.H, y.W, C, mask_mode, ptr(part), s), "yv1_bn_bwd_reduce_pooled")
+    else:
+        check(L.yv1_bn_bwd_reduce(dz.p, dz.ld, zp, zld, y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale),
+                                  ptr(st.shift), y.npix, C, mask_mode, ptr(part), s), "yv1_bn_bwd_reduce")
     part, rows = _shrink_partials(part, rows, 2 * C, dev)
     gb = torch.empty((5, C), dtype=torch.float32, device=dev)     # dgamma, dbeta, k1, k2, k3
     check(L.yv1_bn_bwd_finalize(ptr(part), rows, C, float(y.npix), ptr(bn.weight) if bn is not None else None,
                                 ptr(st.invstd), ptr(gb[0]), ptr(gb[1]), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), s),
           "yv1_bn_bwd_finalize")
+    if pool_idx is not None:
+        check(L.yv1_bn_bwd_apply_pooled(dz.p, dz.ld, ptr(pool_idx), y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale),
+                                        ptr(st.shift), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), y.N, y.H, y.W, C, mask_mode,
+                                        dy.p, dy.ld, s), "yv1_bn_bwd_apply_pooled")
+        return gb[0], gb[1]
     check(L.yv1_bn_bwd_apply(dz.p, dz.ld, zp, zld, y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
                              ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), y.npix, C, mask_mode, dy.p, dy.ld,
                              dres.p if dres is not None else None, dres.ld if dres is not None else 0,
