@@ -175,6 +175,10 @@ int yv1_bn_bwd_apply_pooled(const void* dpool, int lddp, const void* pool_idx, c
 /* idx (nullable): uint8 [N,OH,OW,C] = window position of the first maximum (torch's tie rule), for the backward */
 int yv1_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, void* idx, int N, int H, int W, int C,
                          yv1_stream_t stream);
+/* stems (OriginResNet.py:175-177, OriginDenseNet.py:120-128): pooled = maxpool3x3s2(bf16(relu?(y*scale + shift))) in one
+ * pass -- the values yv1_bn_apply + yv1_maxpool3x3s2_fwd produce, bit for bit, without the intermediate tensor */
+int yv1_bn_act_maxpool3x3s2_fwd(const void* y, int ldy, const float* scale, const float* shift, int relu, void* pooled,
+                                int ldp, void* idx, int N, int H, int W, int C, yv1_stream_t stream);
 /* give idx (fast) or x (the forward input; the first maximum is re-derived) */
 int yv1_maxpool3x3s2_bwd(const void* x, int ldx, const void* idx, const void* dy, int lddy, void* dx, int lddx, int N, int H,
                          int W, int C, yv1_stream_t stream);

@@ -131,16 +131,16 @@ def test_densenet121_every_layer_teacher_forced():
         assert rel <= 1e-2, "%s: rel err %.3g" % (name, rel)
 
     bnf = lambda t, k: F.batch_norm(t, None, None, P[k + ".weight"], P[k + ".bias"], True)
-    xp, y0, s0, z0, H, W = rec["stem"][:6]
+    xp, y0, s0, _, H, W = rec["stem"][:6]
     chk("stem conv", nchw(y0), F.conv2d(x.to(torch.bfloat16).float(), bfw("features.conv0.weight"), stride=2, padding=3))
-    chk("stem bn", nchw(z0), F.relu(bnf(nchw(y0), "features.norm0")))
+    z0 = F.relu(bnf(nchw(y0), "features.norm0"))       # norm0 + relu0 + pool0 are one launch: z0 is never stored
     bi, prev_yc = 0, None
     for st in rec["stages"]:
         if st[0] == "block":
             bi += 1
             _, buf, lrecs, nf = st
             first = nchw(buf, 0, nf)
-            chk("pool into block %d" % bi, first, F.max_pool2d(nchw(z0), 3, 2, 1) if bi == 1 else F.avg_pool2d(prev_yc, 2, 2))
+            chk("pool into block %d" % bi, first, F.max_pool2d(z0, 3, 2, 1) if bi == 1 else F.avg_pool2d(prev_yc, 2, 2))
             for li, (layer, cin, st1, t1, y1, st2, t2) in enumerate(lrecs):
                 p = "features.denseblock%d.denselayer%d" % (bi, li + 1)
                 chk(p + " t1", nchw(t1), F.relu(bnf(nchw(buf, 0, cin), p + ".norm1")))

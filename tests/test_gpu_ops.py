@@ -309,6 +309,32 @@ def test_stem_chain_backward():
     _same_up_to_sum_order(dy0f, dy0, dgf, dg, dbf, db)
 
 
+@pytest.mark.parametrize("N,H,Wd,C,relu", [(2, 15, 17, 64, True), (1, 8, 8, 128, False), (3, 31, 14, 64, True), (16, 224, 224, 64, True)])
+def test_bn_act_maxpool_forward_equals_bn_apply_then_maxpool(N, H, Wd, C, relu):
+    """yv1_bn_act_maxpool3x3s2_fwd == yv1_bn_apply + yv1_maxpool3x3s2_fwd bit for bit (values and argmax codes), also
+    into a channel window of a wider buffer (DenseNet's first block) and with negative BatchNorm scales."""
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(H + Wd + C)
+    y = ops.Act(bf(torch.randn(N, H, Wd, C, generator=g)).to(DEV).to(torch.bfloat16))
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data.uniform_(-1.0, 1.5, generator=g)
+    bn.bias.data.uniform_(-0.3, 0.3, generator=g)
+    bn = bn.to(DEV)
+    st = ops.bn_finalize(ops.bn_stats(y), y.npix, bn)
+    z = ops.new_act(N, H, Wd, C, DEV)
+    ops.bn_apply(y, st, z, relu=relu)
+    OH, OW = (H - 1) // 2 + 1, (Wd - 1) // 2 + 1
+    wide_a = ops.Act(torch.zeros(N, OH, OW, C + 32, dtype=torch.bfloat16, device=DEV))
+    wide_b = ops.Act(torch.zeros(N, OH, OW, C + 32, dtype=torch.bfloat16, device=DEV))
+    idx_a = ops.maxpool_fwd(z, wide_a.window(0, C), want_index=True)
+    idx_b = ops.bn_act_maxpool_fwd(y, st, wide_b.window(0, C), relu=relu, want_index=True)
+    torch.cuda.synchronize()
+    assert torch.equal(wide_a.t, wide_b.t) and torch.equal(idx_a, idx_b)
+    assert ops.bn_act_maxpool_fwd(y, st, wide_b.window(0, C), relu=relu) is None
+    ref = F.max_pool2d(to_nchw(z), 3, 2, 1)
+    np.testing.assert_array_equal(to_nchw(wide_b)[:, :C].numpy(), ref.numpy())
+
+
 @pytest.mark.parametrize("N,H,Wd,C,mode", [(2, 15, 17, 64, 2), (1, 8, 8, 128, 0), (3, 31, 14, 64, 2), (64, 224, 224, 64, 2)])
 def test_bn_backward_behind_maxpool_equals_the_two_kernel_chain(N, H, Wd, C, mode):
     """yv1_bn_bwd_{reduce,apply}_pooled == yv1_maxpool3x3s2_bwd + yv1_bn_bwd_{reduce,apply}, bit for bit: odd and even

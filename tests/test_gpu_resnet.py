@@ -239,10 +239,10 @@ def test_resnet50_every_layer_teacher_forced():
         assert rel <= 1e-2, "%s: rel err %.3g" % (name, rel)
 
     bnf = lambda t, k: F.batch_norm(t, None, None, P[k + ".weight"], P[k + ".bias"], True)
-    xp, y0, s0, z0, H, W = rec["stem"][:6]
+    xp, y0, s0, _, H, W = rec["stem"][:6]
     chk("stem conv", nchw(y0), F.conv2d(x.to(torch.bfloat16).float(), bfw("conv1.weight"), stride=2, padding=3))
-    chk("stem bn", nchw(z0), F.relu(bnf(nchw(y0), "bn1")))
-    chk("maxpool", nchw(rec["blocks"][0][1]), F.max_pool2d(nchw(z0), 3, 2, 1))
+    # bn1 + relu + maxpool are one launch (the BatchNorm output is never stored)
+    chk("stem bn+relu+maxpool", nchw(rec["blocks"][0][1]), F.max_pool2d(F.relu(bnf(nchw(y0), "bn1")), 3, 2, 1))
     names = ["%s.%d" % (st, i) for st in net._stage_names for i in range(len(getattr(net, st)))]
     for name, (blk, xin, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, _m) in zip(names, rec["blocks"]):
         xi = nchw(xin)

@@ -76,6 +76,7 @@ SIGNATURES = {
                                       c_p, c_i, c_p]),
     "yv1_stats_merge": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p]),
     "yv1_maxpool3x3s2_fwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_bn_act_maxpool3x3s2_fwd": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "yv1_maxpool3x3s2_bwd": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "yv1_avgpool2_fwd": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "yv1_avgpool2_bwd": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

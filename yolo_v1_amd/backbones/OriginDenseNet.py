@@ -99,13 +99,11 @@ class DenseNet(HipBackbone):
         xp = ops.pack_input(images)
         y0 = ops.new_act(N, H // 2, W // 2, 64, dev)
         s0 = norm(ops.stem_fwd(xp, w0, y0, H, W), y0.npix, F.norm0)
-        z0 = ops.new_act(N, H // 2, W // 2, 64, dev)
-        ops.bn_apply(y0, s0, z0, relu=True)
-        rec = {"stem": [xp, y0, s0, z0, H, W, None], "stages": []}
+        rec = {"stem": [xp, y0, s0, None, H, W, None], "stages": []}
 
         h, w = H // 4, W // 4
         buf = table = None
-        pending_pool = ("max", z0)
+        pending_pool = ("max", y0)      # norm0 + relu0 + pool0 run as one launch: the BatchNorm output is never stored
         for item in self._plan:
             if item[0] == "block":
                 _, name, nf, nl = item
@@ -113,7 +111,7 @@ class DenseNet(HipBackbone):
                 buf = ops.new_act(N, h, w, ctot, dev)
                 first = buf.window(0, nf)
                 if pending_pool[0] == "max":
-                    rec["stem"][6] = ops.maxpool_fwd(pending_pool[1], first, want_index=save)
+                    rec["stem"][6] = ops.bn_act_maxpool_fwd(pending_pool[1], s0, first, relu=True, want_index=save)
                 else:
                     ops.avgpool_fwd(pending_pool[1], first)
                 table = None

@@ -147,12 +147,10 @@ class ResNet(HipBackbone):
         xp = ops.pack_input(images)
         y0 = ops.new_act(N, H // 2, W // 2, 64, dev)
         s0 = norm(ops.stem_fwd(xp, w0, y0, H, W), y0.npix, self.bn1)
-        z0 = ops.new_act(N, H // 2, W // 2, 64, dev)
-        ops.bn_apply(y0, s0, z0, relu=True)
         x = ops.new_act(N, H // 4, W // 4, 64, dev)
-        pidx = ops.maxpool_fwd(z0, x, want_index=save)
+        pidx = ops.bn_act_maxpool_fwd(y0, s0, x, relu=True, want_index=save)   # BN + ReLU + pool: one launch, z0 never stored
         x8 = ops.quantize_fp8(x) if f8 else None
-        rec["stem"] = (xp, y0, s0, z0, H, W, pidx)
+        rec["stem"] = (xp, y0, s0, None, H, W, pidx)
 
         for blk in self._blocks():
             planes = blk.conv1.out_channels

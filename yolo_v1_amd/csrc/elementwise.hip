@@ -619,6 +619,56 @@ __global__ void __launch_bounds__(256) k_maxpool_bwd(const bf16_t* __restrict__ 
   }
 }
 
+// BatchNorm-apply (+ReLU) + max pool in one pass (the stems): pools z = bf16(relu(y*scale + shift)) -- the tensor
+// k_bn_apply would have stored -- without storing it: the training backward needs y and the argmax codes only.
+__global__ void __launch_bounds__(256) k_bn_act_maxpool_fwd(const bf16_t* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu, bf16_t* __restrict__ out,
+                                                            int ldo, unsigned char* __restrict__ idx, int N, int H, int W, int C) {
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1, CH = C >> 3;
+  const long long total = (long long)N * OH * OW * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const unsigned ui = (unsigned)i;
+    const int cc = (int)(ui % CH) * 8;
+    unsigned t = ui / CH;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float m[8], sc[8], sh[8];
+    unsigned am[8];
+    load8f(scale + cc, sc);
+    load8f(shift + cc, sh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; am[k] = 0; }
+    for (int r = 0; r < 3; ++r) {
+      const int h = oh * 2 - 1 + r;
+      if (h < 0 || h >= H) continue;
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int w = ow * 2 - 1 + s_;
+        if (w < 0 || w >= W) continue;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(y + ((size_t)(n * H + h) * W + w) * ldy + cc), f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = f[k] * sc[k] + sh[k];
+        if (relu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
+        }
+        unpack8(pack8(f), f);                          // the stored precision of z
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (f[k] > m[k]) { m[k] = f[k]; am[k] = r * 3 + s_; }
+      }
+    }
+    *reinterpret_cast<u32x4*>(out + ((size_t)(n * OH + oh) * OW + ow) * ldo + cc) = pack8(m);
+    if (idx) {
+      uint2 o;
+      o.x = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+      o.y = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+      *reinterpret_cast<uint2*>(idx + ((size_t)(n * OH + oh) * OW + ow) * C + cc) = o;
+    }
+  }
+}
+
 // index form: the forward stored, per (window, channel), which of its 9 positions was the first maximum
 __global__ void __launch_bounds__(256) k_maxpool_bwd_idx(const unsigned char* __restrict__ idx, const bf16_t* __restrict__ dy,
                                                          int lddy, bf16_t* __restrict__ dx, int lddx, int N, int H, int W, int C) {
@@ -1093,6 +1143,21 @@ extern "C" int yv1_maxpool3x3s2_bwd(const void* x, int ldx, const void* idx, con
   else
     hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
                        (bf16_t*)dx, lddx, N, H, W, C);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+// pooled [N,OH,OW,*] = maxpool3x3s2(bf16(relu?(y*scale + shift))), idx as yv1_maxpool3x3s2_fwd: the same values as
+// yv1_bn_apply followed by yv1_maxpool3x3s2_fwd, bit for bit, without the intermediate tensor
+extern "C" int yv1_bn_act_maxpool3x3s2_fwd(const void* y, int ldy, const float* scale, const float* shift, int relu, void* pooled,
+                                           int ldp, void* idx, int N, int H, int W, int C, hipStream_t stream) {
+  if (!y || !scale || !shift || !pooled || N <= 0 || H <= 0 || W <= 0 || C <= 0) return YV1_ERR_BAD_ARG;
+  if (C % 8 || ldy % 8 || ldp % 8) return YV1_ERR_UNSUPPORTED;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long total = (long long)N * OH * OW * (C / 8);
+  if (total >= (1ll << 32)) return YV1_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_act_maxpool_fwd, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)y, ldy, scale, shift, relu,
+                     (bf16_t*)pooled, ldp, (unsigned char*)idx, N, H, W, C);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }

@@ -531,6 +531,15 @@ def maxpool_fwd(x, y, want_index=False):
     return idx
 
 
+def bn_act_maxpool_fwd(y, st, out, relu=True, want_index=False):
+    """out = maxpool3x3s2(bf16(relu?(BN(y)))) without materialising the BatchNorm output (stems); returns the argmax
+    index tensor ``bn_backward(..., pool_idx=)`` consumes when ``want_index``."""
+    idx = torch.empty((out.N, out.H, out.W, y.C), dtype=torch.uint8, device=y.t.device) if want_index else None
+    check(lib().yv1_bn_act_maxpool3x3s2_fwd(y.p, y.ld, ptr(st.scale), ptr(st.shift), 1 if relu else 0, out.p, out.ld, ptr(idx),
+                                            y.N, y.H, y.W, y.C, stream_ptr(y.t.device)), "yv1_bn_act_maxpool3x3s2_fwd")
+    return idx
+
+
 def maxpool_bwd(x, dy, dx, idx=None):
     """x: the forward input (used when idx is None); dx has x's geometry."""
     check(lib().yv1_maxpool3x3s2_bwd(x.p if x is not None else None, x.ld if x is not None else 0, ptr(idx), dy.p, dy.ld,
