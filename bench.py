@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--backbone", default="resnet", choices=["resnet", "densenet"])
     ap.add_argument("--S", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-roofline", type=int, default=1,
+                    help="after the timed region, time the dominant kernel family (implicit-GEMM conv) per layer shape and "
+                         "report roofline.dominant_kernel (0 when profiling: keeps the trace to the training steps)")
     ap.add_argument("--host-input", type=int, default=1,
                     help="after the timed region, also time the same steps fed from pinned host memory (fp32 batch per "
                          "step over PCIe, copy stream, one batch ahead) and report it as host_input -- never as value")
@@ -268,7 +271,7 @@ def main():
         }
         if world == 1 and args.host_input and graphed is not None:
             out["host_input"] = host_input_rate(graphed, step, images, target, args.steps)
-        if world == 1 and args.backbone == "resnet" and args.S == 7 and not args.fp8_forward:
+        if world == 1 and args.kernel_roofline and args.backbone == "resnet" and args.S == 7 and not args.fp8_forward:
             out["roofline"]["dominant_kernel"] = conv_kernel_roofline(args.batch, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
