@@ -1093,7 +1093,7 @@ static int bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const 
   a.k1 = k1; a.k2 = k2; a.k3 = k3; a.dy = (bf16_t*)dy; a.lddy = lddy; a.dres = (bf16_t*)dres; a.lddres = lddres;
   a.accumulate = accumulate;
   a.pool_idx = (const unsigned char*)pool_idx; a.pH = pH; a.pW = pW;
-  if (pool_idx && pH % 2 == 0 && pW % 2 == 0) {
+  if (pool_idx && pH % 2 == 0 && pW % 2 == 0 && (npix / 4) * (C / 8) < (1ll << 32)) {   // 32-bit patch index arithmetic
     a.npix = npix / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply_pool2, dim3(ew_blocks(a.npix * (C / 8))), dim3(256), 0, stream, a);
     YV1_LAUNCH_CHECK();
