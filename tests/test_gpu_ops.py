@@ -58,6 +58,9 @@ CONV_CASES = [
     (2, 14, 14, 256, 512, 1, 2, 0),
     (1, 7, 7, 512, 512, 3, 1, 1),
     (2, 7, 9, 96, 128, 1, 1, 0),        # DenseNet: Cin multiple of 32 only
+    (3, 14, 14, 224, 128, 1, 1, 0),     # DenseNet bottleneck: wgrad with a partial last 128-wide Cin tile
+    (2, 28, 28, 352, 128, 1, 1, 0),
+    (2, 14, 14, 160, 128, 1, 1, 0),     # too much padding for that: 32-wide Cin tiles
     (2, 12, 12, 128, 32, 3, 1, 1),      # DenseNet growth conv
     (2, 7, 7, 2048, 30, 1, 1, 0),       # head (Cout padded to 32)
     (9, 28, 28, 128, 128, 3, 1, 1),     # enough tiles for the 128x128 kernel

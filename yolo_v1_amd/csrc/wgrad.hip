@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(WgradArgs a) {
   const int a_row = tid / ACH, a_cc = tid % ACH;
   const int b_row = tid / BCH, b_cc = tid % BCH;
   const bool a_cok = k0 + a_cc * 8 < a.Cout;
+  const bool b_cok = c0 + b_cc * 8 < a.Cin;           // the last Cin tile may be partial (Cin % BNC != 0)
   // x-operand pixel state per pass, advanced incrementally by KP pixels per K-step (no divisions in the loop)
   int xn[B_PASSES], xp[B_PASSES], xq[B_PASSES];
 #pragma unroll
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(WgradArgs a) {
     _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
       const int row = b_row + i * B_ROWSTEP;                                                                     \
       const int ih = xp[i] * a.ah + r * a.bh + a.ch, iw = xq[i] * a.aw + s * a.bw + a.cw;                        \
-      const bool ok = row < KP && ld_m + row < a.M && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW;              \
+      const bool ok = row < KP && ld_m + row < a.M && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW && b_cok;     \
       const size_t off = ok ? ((size_t)(xn[i] * a.IH + ih) * a.IW + iw) * a.ldx + c0 + b_cc * 8 : (size_t)0;     \
       const u32x4 v = *reinterpret_cast<const u32x4*>(a.X + off);                                                \
       const u32x4 z = {0u, 0u, 0u, 0u};                                                                          \
@@ -732,7 +733,12 @@ int wgrad_kp() {
 
 Plan make_plan(int M, int Cin, int Cout, int taps) {
   Plan p;
-  if (Cout % 128 == 0 && Cin % 128 == 0) { p.bmc = 128; p.bnc = 128; }
+  // DenseNet's 1x1 bottlenecks (Cout 128, Cin = 64 + 32 i): a partial last 128-wide Cin tile (masked loads) beats
+  // 32- or 64-wide tiles that re-read dY once per tile, as long as at most a quarter of the tile columns are padding
+  const int cin_pad128 = (Cin + 127) / 128 * 128;
+  if (Cout % 128 == 0 && (Cin % 128 == 0 || (taps == 1 && Cin % 32 == 0 && (cin_pad128 - Cin) * 4 <= cin_pad128))) {
+    p.bmc = 128; p.bnc = 128;
+  }
   else if (Cout % 64 == 0 && Cin % 64 == 0) { p.bmc = 64; p.bnc = 64; }
   else if (Cout <= 32 && Cin % 128 == 0) { p.bmc = 32; p.bnc = 128; }
   else { p.bmc = 128; p.bnc = 32; }
