@@ -69,6 +69,9 @@ CONV_CASES = [
     (2, 20, 40, 64, 64, 3, 1, 1),
     (3, 13, 25, 256, 128, 3, 1, 1),
     (1, 33, 57, 128, 192, 3, 1, 1),
+    # the same kernel on a 32 x 128 (cout x cin) tile: DenseNet growth convolutions on the wide maps
+    (2, 20, 56, 128, 32, 3, 1, 1),
+    (1, 9, 50, 256, 32, 3, 1, 1),
 ]
 
 

@@ -540,16 +540,20 @@ struct W3Args {
   int total_steps, steps_per_split, KT, CT;
 };
 
-template <int KP>
+// BMC x BNC = cout x cin channels of the result tile: 64x64 (2x2 waves) or 32x128 (1x4 waves, DenseNet's growth convs)
+template <int KP, int BMC, int BNC>
 __global__ void __launch_bounds__(256, 2) k_wgrad3x3(W3Args a) {
+  static_assert((BMC / 32) * (BNC / 32) == 4, "four waves, one 32x32 quadrant and nine accumulators each");
   constexpr int HWD = KP + 2;                         // halo width (pixels)
-  constexpr int PITCH = 64 * 2 + 64;                  // 48 dwords: conflict-free transposed reads
-  constexpr int A_BYTES = KP * PITCH, B_BYTES = 3 * HWD * PITCH, STAGE = A_BYTES + B_BYTES;
-  constexpr int HCHUNKS = 3 * HWD * 8, B_PASSES = (HCHUNKS + 255) / 256;
+  // row pitches = 16 or 48 (mod 64) dwords: conflict-free transposed reads (see k_wgrad)
+  constexpr int PA = BMC == 32 ? 64 : BMC * 2 + 64, PB = BNC * 2 + 64;
+  constexpr int ACH = BMC / 8, BCH = BNC / 8, WN = BNC / 32;
+  constexpr int A_BYTES = KP * PA, B_BYTES = 3 * HWD * PB, STAGE = A_BYTES + B_BYTES;
+  constexpr int HCHUNKS = 3 * HWD * BCH, B_PASSES = (HCHUNKS + 255) / 256;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
 
   int b = blockIdx.x;
   {                                                   // XCD-aware (bijective) order: see k_wgrad
@@ -560,7 +564,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad3x3(W3Args a) {
   const int ct = b % a.CT; b /= a.CT;
   const int kt_ = b % a.KT; b /= a.KT;
   const int split = b;
-  const int k0 = kt_ * 64, c0 = ct * 64;
+  const int k0 = kt_ * BMC, c0 = ct * BNC;
   const int step0 = split * a.steps_per_split;
   const int nsteps = min(a.steps_per_split, a.total_steps - step0);
 
@@ -572,15 +576,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad3x3(W3Args a) {
     ld_n = nh / a.H;
     ld_h = nh - ld_n * a.H;
   }
-  const int a_row = tid >> 3, a_cc = tid & 7;
+  const int a_row = tid / ACH, a_cc = tid % ACH;
   int b_hr[B_PASSES], b_j[B_PASSES], b_cc[B_PASSES];
 #pragma unroll
   for (int i = 0; i < B_PASSES; ++i) {
     const int idx = tid + i * 256;
-    const int hr = idx / (HWD * 8), rem = idx - hr * (HWD * 8);
+    const int hr = idx / (HWD * BCH), rem = idx - hr * (HWD * BCH);
     b_hr[i] = idx < HCHUNKS ? hr : -1;
-    b_j[i] = rem >> 3;
-    b_cc[i] = rem & 7;
+    b_j[i] = rem / BCH;
+    b_cc[i] = rem % BCH;
   }
   u32x4 ra, rb[B_PASSES];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -606,9 +610,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad3x3(W3Args a) {
   {                                                                                                              \
     unsigned char* sa_ = smem + (BUF_) * STAGE;                                                                  \
     unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
-    if (a_row < KP) *reinterpret_cast<u32x4*>(sa_ + a_row * PITCH + a_cc * 16) = ra;                             \
+    if (a_row < KP) *reinterpret_cast<u32x4*>(sa_ + a_row * PA + a_cc * 16) = ra;                                \
     _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
-      if (b_hr[i] >= 0) *reinterpret_cast<u32x4*>(sb_ + (b_hr[i] * HWD + b_j[i]) * PITCH + b_cc[i] * 16) = rb[i]; \
+      if (b_hr[i] >= 0) *reinterpret_cast<u32x4*>(sb_ + (b_hr[i] * HWD + b_j[i]) * PB + b_cc[i] * 16) = rb[i]; \
     }                                                                                                            \
   }
 
@@ -631,16 +635,16 @@ __global__ void __launch_bounds__(256, 2) k_wgrad3x3(W3Args a) {
     for (int ks = 0; ks < KP / 16; ++ks) {
       const int prow = ks * 16 + 8 * hh + tq;
       const int acol = (wm * 32 + chan_off) * 2, bcol = (wn * 32 + chan_off) * 2;
-      const bf16x4 alo = lds_read_tr16(sa + prow * PITCH + acol);
-      const bf16x4 ahi = lds_read_tr16(sa + (prow + 4) * PITCH + acol);
+      const bf16x4 alo = lds_read_tr16(sa + prow * PA + acol);
+      const bf16x4 ahi = lds_read_tr16(sa + (prow + 4) * PA + acol);
       const bf16x8 fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int s_ = 0; s_ < 3; ++s_) {
-          const unsigned char* tb = sb + (r * HWD + s_) * PITCH;       // tap (r,s): x[h + r - 1][w + s - 1]
-          const bf16x4 blo = lds_read_tr16(tb + prow * PITCH + bcol);
-          const bf16x4 bhi = lds_read_tr16(tb + (prow + 4) * PITCH + bcol);
+          const unsigned char* tb = sb + (r * HWD + s_) * PB;       // tap (r,s): x[h + r - 1][w + s - 1]
+          const bf16x4 blo = lds_read_tr16(tb + prow * PB + bcol);
+          const bf16x4 bhi = lds_read_tr16(tb + (prow + 4) * PB + bcol);
           const bf16x8 fb = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
           acc[r * 3 + s_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[r * 3 + s_], 0, 0, 0);
         }
@@ -664,7 +668,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad3x3(W3Args a) {
     }
 }
 
-struct Plan3 { bool use; int kp, spr, total_steps, steps, splitK, KT, CT; };
+struct Plan3 { bool use; int kp, spr, total_steps, steps, splitK, KT, CT, bmc; };
 
 Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
   Plan3 p;
@@ -678,15 +682,20 @@ Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int 
   }
   // measured (tools/bench_conv.py): 2.0x on 112x112, 1.3x on 56x56, 1.2x on 28x28; 16-pixel segments (14x14 maps) gain
   // nothing over the generic kernel, so rows shorter than 24 pixels stay there
-  p.use = enabled && k == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0 && W >= 24;
+  const bool square = Cin % 64 == 0 && Cout % 64 == 0 && W >= 24;
+  // DenseNet growth convolutions (Cout 32): one 32x128 tile per 128 input channels.  The result is tiny
+  // (32x9x128 fp32 = 147 KB per slab), so all the parallelism is split-K: worth it on the wide maps only
+  const bool thin = Cout == 32 && Cin % 128 == 0 && W >= 48;
+  p.use = enabled && k == 3 && stride == 1 && pad == 1 && (square || thin);
   if (!p.use) return p;
+  p.bmc = square ? 64 : 32;
   p.kp = 32;
   p.spr = (W + p.kp - 1) / p.kp;
   p.total_steps = N * H * p.spr;
-  p.KT = Cout / 64; p.CT = Cin / 64;
+  p.KT = Cout / p.bmc; p.CT = Cin / (square ? 64 : 128);
   int want = want_blocks / (p.KT * p.CT);
   if (want < 1) want = 1;
-  int maxsplit = p.total_steps / 16;                 // at least 16 K-steps per split
+  int maxsplit = p.total_steps / (square ? 16 : 32);  // at least 16 (32) K-steps per split
   if (maxsplit < 1) maxsplit = 1;
   if (want > maxsplit) want = maxsplit;
   p.steps = (p.total_steps + want - 1) / want;
@@ -694,10 +703,17 @@ Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int 
   return p;
 }
 
-template <int KP>
+template <int KP, int BMC, int BNC>
 int launch3(W3Args& a, int nblocks, hipStream_t stream) {
-  constexpr int STAGE = (KP + 3 * (KP + 2)) * (64 * 2 + 64);
-  hipLaunchKernelGGL((k_wgrad3x3<KP>), dim3(nblocks), dim3(256), 2 * STAGE, stream, a);
+  constexpr int STAGE = KP * (BMC == 32 ? 64 : BMC * 2 + 64) + 3 * (KP + 2) * (BNC * 2 + 64);
+  if (2 * STAGE > 64 * 1024) {
+    static bool once = false;
+    if (!once) {
+      YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3<KP, BMC, BNC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+      once = true;
+    }
+  }
+  hipLaunchKernelGGL((k_wgrad3x3<KP, BMC, BNC>), dim3(nblocks), dim3(256), 2 * STAGE, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
@@ -838,7 +854,7 @@ extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     w.N = N; w.H = IH; w.W = IW; w.ldx = ldx; w.lddy = lddy; w.Cin = Cin; w.Cout = Cout;
     w.SPR = p3.spr; w.total_steps = p3.total_steps; w.steps_per_split = p3.steps; w.KT = p3.KT; w.CT = p3.CT;
     const int nb = p3.splitK * p3.KT * p3.CT;
-    const int rc3 = launch3<32>(w, nb, stream);
+    const int rc3 = p3.bmc == 64 ? launch3<32, 64, 64>(w, nb, stream) : launch3<32, 32, 128>(w, nb, stream);
     if (rc3) return rc3;
     const long long n3 = (long long)Cout * 9 * Cin;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((int)((n3 / 4 + 15) / 16)), dim3(256), 0, stream, (const float*)workspace, dw,
