@@ -255,6 +255,33 @@ def test_head_fwd_bwd():
     np.testing.assert_allclose(db.cpu().numpy(), ref_bn.bias.grad.numpy(), rtol=1e-3, atol=1e-4)
 
 
+def test_multi_tensor_weight_prep_equals_single_tensor_prep():
+    """yv1_prep_weights_multi (LDS-tiled transpose, one launch for many weights) == yv1_prep_weights per tensor, bit for bit:
+    padded Cout (30 -> 32), Cin not a multiple of 64, 3x3 taps, contiguous and channels_last parameter strides."""
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(77)
+    shapes = [(64, 64, 1), (30, 2048, 1), (128, 96, 1), (32, 128, 3), (256, 64, 3), (192, 160, 1), (512, 512, 3)]
+    for cl in (False, True):
+        ws_a, ws_b = [], []
+        for (o, i, k) in shapes:
+            w = torch.randn(o, i, k, k, generator=g).to(DEV)
+            if cl:
+                w = w.contiguous(memory_format=torch.channels_last)
+            pa, pb = torch.nn.Parameter(w.clone(memory_format=torch.preserve_format)), torch.nn.Parameter(w)
+            ws_a.append(ops.ConvWeights(pa, k, 1, k // 2))
+            ws_b.append(ops.ConvWeights(pb, k, 1, k // 2))
+        for cw in ws_a:
+            cw.refresh()
+        ops.refresh_many(ws_b)
+        torch.cuda.synchronize()
+        for cw_a, cw_b, shp in zip(ws_a, ws_b, shapes):
+            assert torch.equal(cw_a.fwd, cw_b.fwd) and torch.equal(cw_a.tr, cw_b.tr), shp
+            ref = torch.zeros(cw_a.Opad, shp[2] * shp[2], cw_a.Ipad)
+            ref[:shp[0], :, :shp[1]] = cw_a.param.detach().cpu().permute(0, 2, 3, 1).reshape(shp[0], -1, shp[1])
+            assert torch.equal(cw_b.fwd.float().cpu(), ref.to(torch.bfloat16).float())
+            assert torch.equal(cw_b.tr.float().cpu(), ref.permute(2, 1, 0).contiguous().to(torch.bfloat16).float())
+
+
 def _same_up_to_sum_order(dy_new, dy_ref, dg_new, dg_ref, db_new, db_ref):
     """The per-channel sums agree to fp32 reordering; dy then differs by at most a bf16 rounding flip."""
     for a_, b_ in ((dg_new, dg_ref), (db_new, db_ref)):

@@ -6,7 +6,14 @@ f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_pack_input' in r['Kernel_Name']]
-seg = rows[idx[-steps]:]
+def step_start(j):
+    """A step begins right after the previous step's last optimizer kernel: the learning-rate fill and the bf16
+    weight re-layout launches precede k_pack_input."""
+    s = j
+    while s > 0 and 'k_sgd' not in rows[s - 1]['Kernel_Name'] and j - s < 16:
+        s -= 1
+    return s if s > 0 and 'k_sgd' in rows[s - 1]['Kernel_Name'] else j
+seg = rows[step_start(idx[-steps]):]
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     return n.split('(')[0][:60]

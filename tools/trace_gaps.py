@@ -5,7 +5,10 @@ import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_pack_input' in r['Kernel_Name']]
-seg = rows[idx[-1]:]
+j = s0 = idx[-1]
+while s0 > 0 and 'k_sgd' not in rows[s0 - 1]['Kernel_Name'] and j - s0 < 16:
+    s0 -= 1                          # the step starts with the lr fill + weight re-layout launches, before k_pack_input
+seg = rows[s0 if s0 > 0 and 'k_sgd' in rows[s0 - 1]['Kernel_Name'] else j:]
 side = lambda n: any(k in n for k in ('k_wgrad', 'k_reduce_slabs', 'k_unpack_stem'))
 short = lambda n: n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:30]
 main = sorted([r for r in seg if not side(r['Kernel_Name'])], key=lambda r: int(r['Start_Timestamp']))

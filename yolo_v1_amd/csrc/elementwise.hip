@@ -855,30 +855,42 @@ struct PrepTable {
   int first_block[PREP_MAX + 1];
   int count;
 };
-constexpr int PREP_ELEMS_PER_BLOCK = 256 * 8;
+// One workgroup re-lays-out a 64 (cout) x 64 (cin) tile of one tap: the transposed copy goes through LDS, so both
+// destinations are written in 128-byte runs (a thread-per-element version scattered 2-byte stores Opad*taps apart
+// for the transposed copy and took 0.68 ms per training step for ResNet-50's 25 M weights).
+constexpr int PREP_TILE = 64;
 
 __global__ void __launch_bounds__(256) k_prep_weights_multi(PrepTable t) {
+  __shared__ bf16_t tile[PREP_TILE][PREP_TILE + 2];
   int ti = 0;
   while (ti + 1 < t.count && (int)blockIdx.x >= t.first_block[ti + 1]) ++ti;
   const int O = t.O[ti], I = t.I[ti], KW = t.K[ti], taps = KW * KW, Opad = t.Opad[ti], Ipad = t.Ipad[ti];
-  const long long total = (long long)Opad * taps * Ipad;
-  const long long base = (long long)(blockIdx.x - t.first_block[ti]) * PREP_ELEMS_PER_BLOCK;
+  const int tilesI = (Ipad + PREP_TILE - 1) / PREP_TILE, tilesO = (Opad + PREP_TILE - 1) / PREP_TILE;
+  int lb = (int)blockIdx.x - t.first_block[ti];
+  const int i0 = (lb % tilesI) * PREP_TILE; lb /= tilesI;
+  const int o0 = (lb % tilesO) * PREP_TILE;
+  const int tap = lb / tilesO;
   const float* __restrict__ w = t.w[ti];
   bf16_t* __restrict__ df = t.dst_fwd[ti];
   bf16_t* __restrict__ dt = t.dst_t[ti];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const long long idx = base + it * 256 + threadIdx.x;
-    if (idx >= total) break;
-    const int i = (int)(idx % Ipad);
-    const long long q = idx / Ipad;
-    const int tap = (int)(q % taps);
-    const int o = (int)(q / taps);
+  const long long so = t.so[ti], si = t.si[ti];
+  const long long tapoff = (tap / KW) * t.sh[ti] + (tap % KW) * t.sw[ti];
+  const int col = threadIdx.x & 63, row0 = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int e = 0; e < PREP_TILE / 4; ++e) {
+    const int o = o0 + e * 4 + row0, i = i0 + col;
     float v = 0.f;
-    if (o < O && i < I) v = w[o * t.so[ti] + i * t.si[ti] + (tap / KW) * t.sh[ti] + (tap % KW) * t.sw[ti]];
-    const bf16_t b = f32_to_bf16(v);
-    df[idx] = b;
-    if (dt) dt[((size_t)i * taps + tap) * Opad + o] = b;
+    if (o < O && i < I) v = w[o * so + i * si + tapoff];
+    const bf16_t bv = f32_to_bf16(v);
+    tile[e * 4 + row0][col] = bv;
+    if (o < Opad && i < Ipad) df[((size_t)o * taps + tap) * Ipad + i] = bv;
+  }
+  if (!dt) return;
+  __syncthreads();
+#pragma unroll 4
+  for (int e = 0; e < PREP_TILE / 4; ++e) {
+    const int i = i0 + e * 4 + row0, o = o0 + col;
+    if (i < Ipad && o < Opad) dt[((size_t)i * taps + tap) * Opad + o] = tile[col][e * 4 + row0];
   }
 }
 
@@ -1225,8 +1237,7 @@ extern "C" int yv1_prep_weights_multi(const float* const* w, const long long* st
     t.so[i] = strides4[4 * i]; t.si[i] = strides4[4 * i + 1]; t.sh[i] = strides4[4 * i + 2]; t.sw[i] = strides4[4 * i + 3];
     t.O[i] = O[i]; t.I[i] = I[i]; t.K[i] = K[i]; t.Opad[i] = Opad[i]; t.Ipad[i] = Ipad[i];
     t.first_block[i] = blocks;
-    const long long total = (long long)Opad[i] * K[i] * K[i] * Ipad[i];
-    blocks += (int)((total + PREP_ELEMS_PER_BLOCK - 1) / PREP_ELEMS_PER_BLOCK);
+    blocks += ((Opad[i] + PREP_TILE - 1) / PREP_TILE) * ((Ipad[i] + PREP_TILE - 1) / PREP_TILE) * K[i] * K[i];
   }
   t.first_block[count] = blocks;
   t.count = count;
