@@ -26,7 +26,6 @@ namespace {
 
 constexpr int NT = 256;          // threads per workgroup
 constexpr int MAXN = 896;        // candidate capacity: sort+mask must fit 160 KiB LDS (decoder needs S*S*B <= 392)
-constexpr int MAXW = MAXN / 64;  // 64-bit words per suppression row
 
 struct Cand {
   float x1, y1, x2, y2, score;
