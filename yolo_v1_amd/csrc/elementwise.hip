@@ -507,6 +507,16 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_pool2(BwdArgs a, int TX) 
 __global__ void __launch_bounds__(256) k_bn_bwd_apply_pool2(BwdArgs a) {
   const int CH = a.C >> 3, OH = a.pH >> 1, OW = a.pW >> 1;
   const long long total = a.npix * CH;                    // a.npix = number of patches
+  // the grid stride is a multiple of CH when CH divides 256 (the stems: CH = 8): a thread then keeps its channel chunk
+  // for the whole loop and the seven per-channel vectors are loaded once
+  const bool fixed_c = (256 % CH) == 0;
+  float mu[8], is[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+  if (fixed_c) {
+    const int c8 = (int)(threadIdx.x % CH) * 8;
+    load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
+    load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+    if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
+  }
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const unsigned ui = (unsigned)i;
     const int c8 = (int)(ui % CH) * 8;
@@ -515,10 +525,11 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_pool2(BwdArgs a) {
     const unsigned pa = t % OH, n = t / OH;
     float g[4][8];
     pooled_patch_grad(a, n, pa, pb, c8, OH, OW, g);
-    float mu[8], is[8], k1[8], k2[8], k3[8], sc[8], sh[8];
-    load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
-    load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
-    if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
+    if (!fixed_c) {
+      load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
+      load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+      if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const size_t p = ((size_t)n * a.pH + 2 * pa + (q >> 1)) * a.pW + 2 * pb + (q & 1);
