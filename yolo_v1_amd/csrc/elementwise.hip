@@ -158,25 +158,39 @@ struct ApplyArgs {
   int ldz8 = 0;
 };
 
+// FIXED_C: the grid stride (256 * gridDim.x) is a multiple of CH (CH divides 256: every ResNet layer), so a thread keeps
+// its 8-channel chunk for the whole loop and the per-channel vectors are loaded once instead of once per 16 bytes of
+// data -- they were 4 (8 with a BatchNorm'ed residual) of the 6 (11) vector-memory instructions of an iteration.
+template <bool FIXED_C>
 __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
   const int CH = a.C >> 3;
   const long long total = a.npix * CH;
+  float sc[8], sh[8], rs[8], rh[8];
+  if (FIXED_C) {
+    const int cc = (int)(threadIdx.x % CH) * 8;
+    load8f(a.scale + cc, sc);
+    load8f(a.shift + cc, sh);
+    if (a.res && a.rscale) { load8f(a.rscale + cc, rs); load8f(a.rshift + cc, rh); }
+  }
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long pix = i / CH;
     const int cc = (int)(i - pix * CH) * 8;
-    float f[8], sc[8], sh[8];
+    float f[8];
     unpack8(*reinterpret_cast<const u32x4*>(a.y + pix * a.ldy + cc), f);
-    load8f(a.scale + cc, sc);
-    load8f(a.shift + cc, sh);
+    if (!FIXED_C) {
+      load8f(a.scale + cc, sc);
+      load8f(a.shift + cc, sh);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = f[k] * sc[k] + sh[k];
     if (a.res) {
       float r[8];
       unpack8(*reinterpret_cast<const u32x4*>(a.res + pix * a.ldr + cc), r);
       if (a.rscale) {
-        float rs[8], rh[8];
-        load8f(a.rscale + cc, rs);
-        load8f(a.rshift + cc, rh);
+        if (!FIXED_C) {
+          load8f(a.rscale + cc, rs);
+          load8f(a.rshift + cc, rh);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) r[k] = r[k] * rs[k] + rh[k];
       }
@@ -310,7 +324,9 @@ __device__ __forceinline__ void pooled_grad(const BwdArgs& a, long long p, int c
   unpack8(pack8(g), g);
 }
 
-__device__ __forceinline__ void masked_grad(const BwdArgs& a, long long p, int c8, const float* yv, float* g) {
+// sc/sh: scale/shift of the channel chunk when the caller already holds them (mask_mode 2), else nullptr
+__device__ __forceinline__ void masked_grad(const BwdArgs& a, long long p, int c8, const float* yv, float* g,
+                                            const float* sc_in = nullptr, const float* sh_in = nullptr) {
   if (a.pool_idx) pooled_grad(a, p, c8, g);
   else unpack8(*reinterpret_cast<const u32x4*>(a.dz + p * a.lddz + c8), g);
   if (a.mask_mode == 1) {
@@ -324,8 +340,13 @@ __device__ __forceinline__ void masked_grad(const BwdArgs& a, long long p, int c
     for (int k = 0; k < 8; ++k) g[k] = ((m >> k) & 1u) ? g[k] : 0.f;
   } else if (a.mask_mode == 2) {
     float sc[8], sh[8];
-    load8f(a.scale + c8, sc);
-    load8f(a.shift + c8, sh);
+    if (sc_in) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sc[k] = sc_in[k]; sh[k] = sh_in[k]; }
+    } else {
+      load8f(a.scale + c8, sc);
+      load8f(a.shift + c8, sh);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) g[k] = (yv[k] * sc[k] + sh[k]) > 0.f ? g[k] : 0.f;
   }
@@ -336,13 +357,16 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
   const int CH = a.C >> 3, TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   float acc[NCOL][2][8];
-  float mu[NCOL][8], is[NCOL][8];
+  float mu[NCOL][8], is[NCOL][8], sc[NCOL][8], sh[NCOL][8];
 #pragma unroll
   for (int j = 0; j < NCOL; ++j) {
     const int col = tx + j * TX;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { acc[j][0][k] = 0.f; acc[j][1][k] = 0.f; mu[j][k] = 0.f; is[j][k] = 0.f; }
-    if (col < CH) { load8f(a.mean + col * 8, mu[j]); load8f(a.invstd + col * 8, is[j]); }
+    for (int k = 0; k < 8; ++k) { acc[j][0][k] = 0.f; acc[j][1][k] = 0.f; mu[j][k] = 0.f; is[j][k] = 0.f; sc[j][k] = 0.f; sh[j][k] = 0.f; }
+    if (col < CH) {
+      load8f(a.mean + col * 8, mu[j]); load8f(a.invstd + col * 8, is[j]);
+      if (a.mask_mode == 2) { load8f(a.scale + col * 8, sc[j]); load8f(a.shift + col * 8, sh[j]); }
+    }
   }
   const long long p0 = (long long)blockIdx.x * a.pix_per_block;
   const long long p1 = min(a.npix, p0 + a.pix_per_block);
@@ -354,7 +378,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
       if (col < CH) {
         float yv[8], g[8];
         unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + col * 8), yv);
-        masked_grad(a, p, col * 8, yv, g);
+        masked_grad(a, p, col * 8, yv, g, sc[j], sh[j]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           acc[j][0][k] += g[k];
@@ -408,18 +432,29 @@ __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restric
   k3[c] = a1 * sx / count;
 }
 
+template <bool FIXED_C>                                  // see k_bn_apply: 10 (14) of 14 (18) memory instructions were these
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
   const int CH = a.C >> 3;
   const long long total = a.npix * CH;
+  float mu[8], is[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+  if (FIXED_C) {
+    const int c8 = (int)(threadIdx.x % CH) * 8;
+    load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
+    load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+    if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
+  }
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long p = i / CH;
     const int c8 = (int)(i - p * CH) * 8;
-    float yv[8], g[8], mu[8], is[8], k1[8], k2[8], k3[8];
+    float yv[8], g[8];
     unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8), yv);
-    masked_grad(a, p, c8, yv, g);
+    if (FIXED_C) masked_grad(a, p, c8, yv, g, sc, sh);
+    else masked_grad(a, p, c8, yv, g);
     if (a.dres) *reinterpret_cast<u32x4*>(a.dres + p * a.lddres + c8) = pack8(g);
-    load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
-    load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+    if (!FIXED_C) {
+      load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
+      load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+    }
     float o[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = k1[k] * g[k] - k2[k] - (yv[k] - mu[k]) * is[k] * k3[k];
@@ -975,7 +1010,8 @@ static int bn_apply_launch(const void* y, int ldy, void* z, int ldz, const void*
   a.y = (const bf16_t*)y; a.ldy = ldy; a.z = (bf16_t*)z; a.ldz = ldz; a.res = (const bf16_t*)residual; a.ldr = ldr;
   a.scale = scale; a.shift = shift; a.rscale = res_scale; a.rshift = res_shift; a.npix = npix; a.C = C; a.relu = relu;
   a.relu_mask = (unsigned char*)relu_mask; a.z8 = (unsigned char*)z8; a.ldz8 = ldz8;
-  hipLaunchKernelGGL(k_bn_apply, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
+  if (256 % (C / 8) == 0) hipLaunchKernelGGL(k_bn_apply<true>, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_bn_apply<false>, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
@@ -1122,7 +1158,8 @@ static int bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const 
     YV1_LAUNCH_CHECK();
     return YV1_OK;
   }
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
+  if (256 % (C / 8) == 0) hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
