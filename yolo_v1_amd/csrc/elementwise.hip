@@ -158,8 +158,8 @@ struct ApplyArgs {
   int ldz8 = 0;
 };
 
-// FIXED_C: the grid stride (256 * gridDim.x) is a multiple of CH (CH divides 256: every ResNet layer), so a thread keeps
-// its 8-channel chunk for the whole loop and the per-channel vectors are loaded once instead of once per 16 bytes of
+// FIXED_C: the grid stride (256 * gridDim.x) is a multiple of CH (the host rounds the grid: fixed_chunk_grid), so a thread
+// keeps its 8-channel chunk for the whole loop and the per-channel vectors are loaded once instead of once per 16 bytes of
 // data -- they were 4 (8 with a BatchNorm'ed residual) of the 6 (11) vector-memory instructions of an iteration.
 template <bool FIXED_C>
 __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
   const long long total = a.npix * CH;
   float sc[8], sh[8], rs[8], rh[8];
   if (FIXED_C) {
-    const int cc = (int)(threadIdx.x % CH) * 8;
+    const int cc = (int)((blockIdx.x * 256u + threadIdx.x) % CH) * 8;
     load8f(a.scale + cc, sc);
     load8f(a.shift + cc, sh);
     if (a.res && a.rscale) { load8f(a.rscale + cc, rs); load8f(a.rshift + cc, rh); }
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
   const long long total = a.npix * CH;
   float mu[8], is[8], k1[8], k2[8], k3[8], sc[8], sh[8];
   if (FIXED_C) {
-    const int c8 = (int)(threadIdx.x % CH) * 8;
+    const int c8 = (int)((blockIdx.x * 256u + threadIdx.x) % CH) * 8;
     load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
     load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
     if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
@@ -941,6 +941,18 @@ __global__ void __launch_bounds__(256) k_prep_weights_multi(PrepTable t) {
 }
 
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+// grid for the elementwise BatchNorm kernels: rounded down to a multiple of CH / gcd(CH, 256) so that the grid stride
+// keeps every thread on one channel chunk (any C: DenseNet's 96, 160, ... too); *fixed says whether that holds
+int ew_blocks(long long total);
+int fixed_chunk_grid(long long total, int CH, bool* fixed) {
+  int blocks = ew_blocks(total);
+  int g = CH, b = 256;
+  while (b) { const int t = g % b; g = b; b = t; }      // gcd(CH, 256)
+  const int m = CH / g;
+  if (blocks >= m) blocks -= blocks % m;
+  *fixed = ((long long)blocks * 256) % CH == 0;
+  return blocks;
+}
 int ew_blocks(long long total) { long long b = (total + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -1010,8 +1022,10 @@ static int bn_apply_launch(const void* y, int ldy, void* z, int ldz, const void*
   a.y = (const bf16_t*)y; a.ldy = ldy; a.z = (bf16_t*)z; a.ldz = ldz; a.res = (const bf16_t*)residual; a.ldr = ldr;
   a.scale = scale; a.shift = shift; a.rscale = res_scale; a.rshift = res_shift; a.npix = npix; a.C = C; a.relu = relu;
   a.relu_mask = (unsigned char*)relu_mask; a.z8 = (unsigned char*)z8; a.ldz8 = ldz8;
-  if (256 % (C / 8) == 0) hipLaunchKernelGGL(k_bn_apply<true>, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(k_bn_apply<false>, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
+  bool fixed;
+  const int blocks = fixed_chunk_grid(npix * (C / 8), C / 8, &fixed);
+  if (fixed) hipLaunchKernelGGL(k_bn_apply<true>, dim3(blocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_bn_apply<false>, dim3(blocks), dim3(256), 0, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
@@ -1158,8 +1172,10 @@ static int bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const 
     YV1_LAUNCH_CHECK();
     return YV1_OK;
   }
-  if (256 % (C / 8) == 0) hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, stream, a);
+  bool fixed;
+  const int blocks = fixed_chunk_grid(npix * (C / 8), C / 8, &fixed);
+  if (fixed) hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(blocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(blocks), dim3(256), 0, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
