@@ -172,9 +172,14 @@ __global__ void __launch_bounds__(256) k_bn_apply(ApplyArgs a) {
     load8f(a.shift + cc, sh);
     if (a.res && a.rscale) { load8f(a.rscale + cc, rs); load8f(a.rshift + cc, rh); }
   }
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long pix = i / CH;
-    const int cc = (int)(i - pix * CH) * 8;
+  // FIXED_C: the pixel index advances by a constant (grid stride / CH) -- no 64-bit division per 16 bytes of data
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+  const long long dpix = FIXED_C ? (long long)gridDim.x * 256 / CH : 0;
+  long long pix_f = i0 / (unsigned)CH;
+  const int cc_f = (int)(i0 % (unsigned)CH) * 8;
+  for (long long i = i0; FIXED_C ? pix_f < a.npix : i < total; i += (long long)gridDim.x * 256, pix_f += dpix) {
+    const long long pix = FIXED_C ? pix_f : i / CH;
+    const int cc = FIXED_C ? cc_f : (int)(i - pix * CH) * 8;
     float f[8];
     unpack8(*reinterpret_cast<const u32x4*>(a.y + pix * a.ldy + cc), f);
     if (!FIXED_C) {
@@ -443,9 +448,13 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
     load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
     if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
   }
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long p = i / CH;
-    const int c8 = (int)(i - p * CH) * 8;
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+  const long long dpix = FIXED_C ? (long long)gridDim.x * 256 / CH : 0;
+  long long pix_f = i0 / (unsigned)CH;
+  const int cc_f = (int)(i0 % (unsigned)CH) * 8;
+  for (long long i = i0; FIXED_C ? pix_f < a.npix : i < total; i += (long long)gridDim.x * 256, pix_f += dpix) {
+    const long long p = FIXED_C ? pix_f : i / CH;
+    const int c8 = FIXED_C ? cc_f : (int)(i - p * CH) * 8;
     float yv[8], g[8];
     unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8), yv);
     if (FIXED_C) masked_grad(a, p, c8, yv, g, sc, sh);
