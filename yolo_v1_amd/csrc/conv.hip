@@ -414,7 +414,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) 
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations stay in SGPRs
   const int wm = wid / WN, wn = wid % WN;
   int mt, nt;
   {
@@ -452,36 +453,39 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) 
   // wave-uniform LDS byte offsets of this wave's 1 KB pieces inside a stage
   const int piece_row0 = (wid * 64) / CPR;
 
-  int ld_r = 0, ld_s = 0, ld_cb = 0, wtap_off = 0;
-  int aoff[A_PASSES];
-  unsigned avalid = 0;
+  // Loader state: one source pointer per DMA pass, advanced by BK channels per K-step inside a tap and recomputed when
+  // the tap changes; a padding row points at the zero page and does not advance.  (The first version rebuilt every
+  // address from integer offsets and re-selected the zero page in every K-step: ~130 scalar/vector instructions
+  // around 8 MFMAs.)
+  int ld_r = 0, ld_s = 0, ld_cb = 0;
+  const bf16_t* asrc[A_PASSES];
+  int astep[A_PASSES];
+  const bf16_t* wsrc[B_PASSES];
   const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
 #define YV1_SET_TAP_D()                                                                                          \
   {                                                                                                              \
-    avalid = 0;                                                                                                  \
-    wtap_off = ((a.wr0 + ld_r * a.wrs) * a.WS + (a.ws0 + ld_s * a.wss)) * a.Cin;                                 \
+    const int wtap_off = ((a.wr0 + ld_r * a.wrs) * a.WS + (a.ws0 + ld_s * a.wss)) * a.Cin;                       \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
       const int hn = ph[i] + ld_r * a.bh, wn_ = qw[i] + ld_s * a.bw;                                             \
       const int ih = hn >> a.log2d, iw = wn_ >> a.log2d;                                                         \
       const bool ok = pix_base[i] >= 0 && ((hn | wn_) & dmask) == 0 && hn >= 0 && wn_ >= 0 && ih < a.IH &&       \
                       iw < a.IW;                                                                                 \
-      aoff[i] = ok ? (pix_base[i] + ih * a.IW + iw) * a.ldx + lchunk * 8 : 0;                                    \
-      avalid |= ok ? (1u << i) : 0u;                                                                             \
+      asrc[i] = ok ? a.X + ((size_t)(pix_base[i] + ih * a.IW + iw) * a.ldx + lchunk * 8) : zsrc;                 \
+      astep[i] = ok ? BK : 0;                                                                                    \
     }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) wsrc[i] = a.W + (woff[i] + wtap_off);                   \
   }
 #define YV1_ISSUE(STG_)                                                                                          \
   {                                                                                                              \
     unsigned char* sa_ = smem + (STG_) * STAGE;                                                                  \
     unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
-    const int coff = ld_cb * BK;                                                                                 \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
-      const bool ok = (avalid >> i) & 1u;                                                                        \
-      const bf16_t* src = ok ? a.X + (aoff[i] + coff) : zsrc;                                                    \
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sa_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_void*)asrc[i], (lds_void*)(sa_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+      asrc[i] += astep[i];                                                                                       \
     }                                                                                                            \
     _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
-      const bf16_t* src = a.W + (woff[i] + wtap_off + coff);                                                     \
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sb_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_void*)wsrc[i], (lds_void*)(sb_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+      wsrc[i] += BK;                                                                                             \
     }                                                                                                            \
     if (++ld_cb == cblocks) {                                                                                    \
       ld_cb = 0;                                                                                                 \
@@ -504,9 +508,57 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) 
   for (int p = 0; p < NST - 1; ++p)
     if (p < nk) YV1_ISSUE(p);
 
+  // per-lane byte offsets of the MFMA fragments inside a stage (row and swizzled chunk): computed once, the stage base
+  // is a compile-time constant in the unrolled loop below, so every fragment read is `ds_read_b128 v, offset:imm`
   const int l31 = lane & 31, lh = lane >> 5;
-  int cur = 0, nxt = NST - 1;                          // stage read now / stage the next issue fills
-  for (int kt = 0; kt < nk; ++kt) {
+  constexpr int KS = BK / 16;
+  int fa_off[TM][KS], fb_off[TN][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (BM / WM) + i * 32 + l31;
+      fa_off[i][ks] = row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * (BN / WN) + j * 32 + l31;
+      fb_off[j][ks] = A_BYTES + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16;
+    }
+  }
+#define YV1_MFMA_BLOCK(BASE_)                                                                                    \
+  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                            \
+    bf16x8 fa[TM], fb[TN];                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>((BASE_) + fa_off[i][ks]); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>((BASE_) + fb_off[j][ks]); \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);                   \
+  }
+
+  int kt = 0;
+  // steady state, unrolled over the ring: stage indices are constants, NST-2 younger K-steps stay in flight, every
+  // step issues the one NST-1 ahead.  Covers kt < nk - (NST-1) in groups of NST.
+  if (!a.dbg) {
+    const int n_main = nk - (NST - 1);
+    for (; kt + NST <= n_main; kt += NST) {
+#pragma unroll
+      for (int c = 0; c < NST; ++c) {
+        // every fragment read of the previous step must have COMPLETED before the barrier: the DMA issued right after it
+        // refills that stage.  s_barrier alone is not a memory fence to the compiler -- with loop-invariant fragment
+        // addresses it scheduled the last ds_reads of a step above the barrier and their lgkmcnt wait below it (a
+        // run-to-run race).  The asm is a compiler barrier for memory operations and the wait itself.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<(NST - 2) * LPS>();
+        __builtin_amdgcn_s_barrier();                  // everyone's pieces of this step landed; everyone left the stage refilled next
+        YV1_ISSUE((c + NST - 1) % NST);
+        YV1_MFMA_BLOCK(smem + c * STAGE);
+      }
+    }
+  }
+  // remaining steps (fewer than NST that still issue, then the NST-1 that only drain): runtime stage index
+  int cur = 0, nxt = NST - 1;                          // kt is a multiple of NST here
+  for (; kt < nk; ++kt) {
     // retire K-step kt: the younger in-flight steps (at most NST-2 of them) may stay outstanding
     const int younger = min(nk - 1 - kt, NST - 2);
     if (younger >= 2) wait_vmcnt<2 * LPS>();
@@ -514,31 +566,12 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) 
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                      // everyone's pieces of step kt landed; everyone left stage nxt
     if (kt + NST - 1 < nk && !(a.dbg & 1)) YV1_ISSUE(nxt);
-    const unsigned char* sa = smem + cur * STAGE;
-    const unsigned char* sb = sa + A_BYTES;
-    if (!(a.dbg & 2))
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (BM / WM) + i * 32 + l31;
-        fa[i] = *reinterpret_cast<const bf16x8*>(sa + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * (BN / WN) + j * 32 + l31;
-        fb[j] = *reinterpret_cast<const bf16x8*>(sb + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
+    if (!(a.dbg & 2)) YV1_MFMA_BLOCK(smem + cur * STAGE);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads complete before the next barrier (see above)
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
+#undef YV1_MFMA_BLOCK
 #undef YV1_SET_TAP_D
 #undef YV1_ISSUE
   __syncthreads();                                     // all fragment reads done before the epilogue tile reuses LDS

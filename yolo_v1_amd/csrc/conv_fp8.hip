@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
                                                                       0x7f7f7f7f);
     }
+    // fragment reads complete (and are not scheduled below) the next barrier: the DMA after it refills this stage.
+    // s_barrier alone is no memory fence to the compiler (see conv.hip).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }

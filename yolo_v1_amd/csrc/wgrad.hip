@@ -350,6 +350,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    // fragment reads complete (and are not scheduled below) the next barrier: the DMA after it refills this stage.
+    // s_barrier alone is no memory fence to the compiler (see conv.hip).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
