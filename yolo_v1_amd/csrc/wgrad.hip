@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: DMA destinations stay in SGPRs
   const int wm = wid >> 1, wn = wid & 1;
 
   int b = blockIdx.x;
@@ -282,25 +283,43 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
     const int n = m / PQ, rem = m - n * PQ;
     xn[i] = n; xp[i] = rem / a.Q; xq[i] = rem - xp[i] * a.Q;
   }
-  int ld_m = step0 * KP;
+  // Loader state.  dY rows are consecutive pixels: one pointer per piece, advanced by KP pixels per K-step.  The X rows
+  // are too when the convolution has stride 1 (every 1x1 layer but the four projection shortcuts): `lin`; otherwise
+  // the (n, p, q) state of the generic kernel is kept.  Rows past M read the zero page.
+  const bool lin = a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0;
+  int mrow[PPW];
+  const bf16_t* pa[PPW];
+  const bf16_t* pb[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    mrow[i] = step0 * KP + (wid + 4 * i) * RPP + lrow;
+    pa[i] = a.DY + ((size_t)mrow[i] * a.lddy + k0 + lchunk * 8);
+    pb[i] = a.X + ((size_t)mrow[i] * a.ldx + c0 + lchunk * 8);
+  }
+  const size_t stepa = (size_t)KP * a.lddy, stepb = (size_t)KP * a.ldx;
 #define YV1_WGD_ISSUE(STG_)                                                                                      \
   {                                                                                                              \
     unsigned char* sa_ = smem + (STG_) * STAGE;                                                                  \
     unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                            \
       const int piece = wid + 4 * i;                                                                             \
-      const int m = ld_m + piece * RPP + lrow;                                                                   \
-      const bf16_t* srca = m < a.M ? a.DY + ((size_t)m * a.lddy + k0 + lchunk * 8) : zsrc;                       \
+      const bool inm = mrow[i] < a.M;                                                                            \
+      const bf16_t* srca = inm ? pa[i] : zsrc;                                                                   \
       __builtin_amdgcn_global_load_lds((glb_void*)srca, (lds_void*)(sa_ + piece * 1024), 16, 0, 0);              \
-      const int ih = xp[i] * a.ah + r * a.bh + a.ch, iw = xq[i] * a.aw + s * a.bw + a.cw;                        \
-      const bool ok = m < a.M && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW;                                   \
-      const bf16_t* srcb = ok ? a.X + (((size_t)(xn[i] * a.IH + ih) * a.IW + iw) * a.ldx + c0 + lchunk * 8) : zsrc; \
+      const bf16_t* srcb;                                                                                        \
+      if (lin) {                                                                                                 \
+        srcb = inm ? pb[i] : zsrc;                                                                               \
+      } else {                                                                                                   \
+        const int ih = xp[i] * a.ah + r * a.bh + a.ch, iw = xq[i] * a.aw + s * a.bw + a.cw;                      \
+        const bool ok = inm && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW;                                     \
+        srcb = ok ? a.X + (((size_t)(xn[i] * a.IH + ih) * a.IW + iw) * a.ldx + c0 + lchunk * 8) : zsrc;          \
+        xq[i] += KP;                                                                                             \
+        while (xq[i] >= a.Q) { xq[i] -= a.Q; ++xp[i]; }                                                          \
+        while (xp[i] >= a.P) { xp[i] -= a.P; ++xn[i]; }                                                          \
+      }                                                                                                          \
       __builtin_amdgcn_global_load_lds((glb_void*)srcb, (lds_void*)(sb_ + piece * 1024), 16, 0, 0);              \
-      xq[i] += KP;                                                                                               \
-      while (xq[i] >= a.Q) { xq[i] -= a.Q; ++xp[i]; }                                                            \
-      while (xp[i] >= a.P) { xp[i] -= a.P; ++xn[i]; }                                                            \
+      pa[i] += stepa; pb[i] += stepb; mrow[i] += KP;                                                             \
     }                                                                                                            \
-    ld_m += KP;                                                                                                  \
   }
 
   f32x16 acc[TM][TN];
@@ -316,46 +335,64 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
   const int h = g >> 1;
   const int chan_off = 16 * (g & 1) + 4 * tp;
   const int xr = tq << SEGSH;                          // (pixel row & 3) << SEGSH: the row's XOR, in bytes
+  // per-lane byte offsets of the transposed fragment reads inside a stage, computed once (the stage base is an
+  // immediate in the unrolled loop)
+  constexpr int KS = KP / 16;
+  int fa_off[TM][KS], fb_off[TN][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int prow = ks * 16 + 8 * h + tq;             // prow & 3 == tq, also for prow + 4
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa_off[i][ks] = prow * ROWB + (((wm * (BT / 2) + i * 32 + chan_off) * 2) ^ xr);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb_off[j][ks] = A_BYTES + prow * ROWB + (((wn * (BT / 2) + j * 32 + chan_off) * 2) ^ xr);
+  }
+#define YV1_WGD_MFMA(BASE_)                                                                                      \
+  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                            \
+    bf16x8 fa[TM], fb[TN];                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                             \
+      const bf16x4 lo = lds_read_tr16((BASE_) + fa_off[i][ks]);                                                  \
+      const bf16x4 hi = lds_read_tr16((BASE_) + fa_off[i][ks] + 4 * ROWB);                                       \
+      fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                                           \
+    }                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                             \
+      const bf16x4 lo = lds_read_tr16((BASE_) + fb_off[j][ks]);                                                  \
+      const bf16x4 hi = lds_read_tr16((BASE_) + fb_off[j][ks] + 4 * ROWB);                                       \
+      fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                                           \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);                   \
+  }
 
   if (nsteps > 0) YV1_WGD_ISSUE(0);
   if (nsteps > 1) YV1_WGD_ISSUE(1);
-  int cur = 0, nxt = 2;
-  for (int st = 0; st < nsteps; ++st) {
+  int st = 0;
+  // steady state, unrolled over the three-stage ring (constant stage indices): one K-step stays in flight, every step
+  // issues the one two ahead
+  for (; st + NST <= nsteps - 2; st += NST) {
+#pragma unroll
+    for (int c = 0; c < NST; ++c) {
+      // fragment reads of the previous step complete (and are not scheduled below) the barrier: the DMA after it refills
+      // that stage.  s_barrier alone is no memory fence to the compiler (see conv.hip).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wg_wait_vmcnt<LPS>();
+      __builtin_amdgcn_s_barrier();
+      YV1_WGD_ISSUE((c + 2) % NST);
+      YV1_WGD_MFMA(smem + c * STAGE);
+    }
+  }
+  int cur = 0, nxt = 2;                                // st is a multiple of NST here
+  for (; st < nsteps; ++st) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (st + 1 < nsteps) wg_wait_vmcnt<LPS>(); else wg_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (st + 2 < nsteps) YV1_WGD_ISSUE(nxt);
-    const unsigned char* sa = smem + cur * STAGE;
-    const unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KP / 16; ++ks) {
-      const int prow = ks * 16 + 8 * h + tq;           // prow & 3 == tq, also for prow + 4
-      bf16x8 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int colb = ((wm * (BT / 2) + i * 32 + chan_off) * 2) ^ xr;
-        const bf16x4 lo = lds_read_tr16(sa + prow * ROWB + colb);
-        const bf16x4 hi = lds_read_tr16(sa + (prow + 4) * ROWB + colb);
-        fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int colb = ((wn * (BT / 2) + j * 32 + chan_off) * 2) ^ xr;
-        const bf16x4 lo = lds_read_tr16(sb + prow * ROWB + colb);
-        const bf16x4 hi = lds_read_tr16(sb + (prow + 4) * ROWB + colb);
-        fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    // fragment reads complete (and are not scheduled below) the next barrier: the DMA after it refills this stage.
-    // s_barrier alone is no memory fence to the compiler (see conv.hip).
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    YV1_WGD_MFMA(smem + cur * STAGE);
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
+#undef YV1_WGD_MFMA
 #undef YV1_WGD_ISSUE
 
   const int l31 = lane & 31, lh = lane >> 5;
