@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
     pa[i] = a.DY + ((size_t)mrow[i] * a.lddy + k0 + lchunk * 8);
     pb[i] = a.X + ((size_t)mrow[i] * a.ldx + c0 + lchunk * 8);
   }
+  const bool cok = c0 + lchunk * 8 < a.Cin;            // partial last Cin tile (DenseNet bottlenecks): those lanes read zeros
   const size_t stepa = (size_t)KP * a.lddy, stepb = (size_t)KP * a.ldx;
 #define YV1_WGD_ISSUE(STG_)                                                                                      \
   {                                                                                                              \
@@ -308,10 +309,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
       __builtin_amdgcn_global_load_lds((glb_void*)srca, (lds_void*)(sa_ + piece * 1024), 16, 0, 0);              \
       const bf16_t* srcb;                                                                                        \
       if (lin) {                                                                                                 \
-        srcb = inm ? pb[i] : zsrc;                                                                               \
+        srcb = (inm && cok) ? pb[i] : zsrc;                                                                      \
       } else {                                                                                                   \
         const int ih = xp[i] * a.ah + r * a.bh + a.ch, iw = xq[i] * a.aw + s * a.bw + a.cw;                      \
-        const bool ok = inm && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW;                                     \
+        const bool ok = inm && cok && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW;                              \
         srcb = ok ? a.X + (((size_t)(xn[i] * a.IH + ih) * a.IW + iw) * a.ldx + c0 + lchunk * 8) : zsrc;          \
         xq[i] += KP;                                                                                             \
         while (xq[i] >= a.Q) { xq[i] -= a.Q; ++xp[i]; }                                                          \
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k = k0 + wm * (BT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        out[(size_t)k * Ktot + (size_t)tap * a.Cin + c] = acc[i][j][e];
+        if (c < a.Cin) out[(size_t)k * Ktot + (size_t)tap * a.Cin + c] = acc[i][j][e];
       }
     }
 }
@@ -835,8 +836,8 @@ int run_plan(const Plan& p, WgradArgs& a, int nblocks, hipStream_t stream) {
     static int dma = -1;                     // YV1_WGRAD_DMA=0: register-staged loop
     if (dma < 0) { const char* e = getenv("YV1_WGRAD_DMA"); dma = e ? atoi(e) : 1; }
     // measured: 5-12 % faster on the 1x1 layers, slower on the per-tap workgroups of 3x3 layers -> 1x1 only
-    if (dma && a.R * a.S == 1 && p.kp == 32 && p.bmc == p.bnc && (p.bmc == 128 || p.bmc == 64) && a.Cout % p.bmc == 0 && a.Cin % p.bnc == 0 &&
-        a.lddy % 8 == 0 && a.ldx % 8 == 0) {
+    if (dma && a.R * a.S == 1 && p.kp == 32 && p.bmc == p.bnc && (p.bmc == 128 || p.bmc == 64) && a.Cout % p.bmc == 0 &&
+        (a.Cin % p.bnc == 0 || (p.bmc == 128 && a.Cin % 8 == 0)) && a.lddy % 8 == 0 && a.ldx % 8 == 0) {
       if (p.bmc == 128) {
         static bool once = false;
         if (!once) {
