@@ -87,7 +87,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: DMA destinations stay in SGPRs
   const int wm = wid / WN, wn = wid % WN;
 
   int mt, nt;
@@ -125,34 +126,35 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
   for (int i = 0; i < B_PASSES; ++i) woff[i] = (n0 + rrow + i * RPP) * Ktot + lchunk * 16;
   const int piece_row0 = (wid * 64) / CPR;
 
-  int ld_r = 0, ld_s = 0, ld_cb = 0, wtap_off = 0;
-  int aoff[A_PASSES];
-  unsigned avalid = 0;
+  // loader state as in conv.hip's k_conv_dma: one source pointer per DMA pass, advanced by BKB bytes per K-step inside a
+  // tap, recomputed when the tap changes; padding rows point at the zero page and do not advance
+  int ld_r = 0, ld_s = 0, ld_cb = 0;
+  const unsigned char* asrc[A_PASSES];
+  int astep[A_PASSES];
+  const unsigned char* wsrc[B_PASSES];
   const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(g_zero_page8);
 #define YV1_SET_TAP8()                                                                       \
   {                                                                                          \
-    avalid = 0;                                                                              \
-    wtap_off = (ld_r * a.KS + ld_s) * a.Cin;                                                 \
+    const int wtap_off = (ld_r * a.KS + ld_s) * a.Cin;                                       \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                   \
       const int ih = ph[i] + ld_r, iw = qw[i] + ld_s;                                        \
       const bool ok = pix_base[i] >= 0 && ih >= 0 && iw >= 0 && ih < a.IH && iw < a.IW;      \
-      aoff[i] = ok ? (pix_base[i] + ih * a.IW + iw) * a.ldx + lchunk * 16 : 0;               \
-      avalid |= ok ? (1u << i) : 0u;                                                         \
+      asrc[i] = ok ? a.X + ((size_t)(pix_base[i] + ih * a.IW + iw) * a.ldx + lchunk * 16) : zsrc; \
+      astep[i] = ok ? BKB : 0;                                                               \
     }                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) wsrc[i] = a.W + (woff[i] + wtap_off); \
   }
 #define YV1_ISSUE8(STG_)                                                                     \
   {                                                                                          \
     unsigned char* sa_ = smem + (STG_) * STAGE;                                              \
     unsigned char* sb_ = sa_ + A_BYTES;                                                      \
-    const int coff = ld_cb * BKB;                                                            \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                   \
-      const bool ok = (avalid >> i) & 1u;                                                    \
-      const unsigned char* src = ok ? a.X + (aoff[i] + coff) : zsrc;                         \
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sa_ + (piece_row0 + i * RPP) * BKB), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_void*)asrc[i], (lds_void*)(sa_ + (piece_row0 + i * RPP) * BKB), 16, 0, 0); \
+      asrc[i] += astep[i];                                                                   \
     }                                                                                        \
     _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                   \
-      const unsigned char* src = a.W + (woff[i] + wtap_off + coff);                          \
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sb_ + (piece_row0 + i * RPP) * BKB), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_void*)wsrc[i], (lds_void*)(sb_ + (piece_row0 + i * RPP) * BKB), 16, 0, 0); \
+      wsrc[i] += BKB;                                                                        \
     }                                                                                        \
     if (++ld_cb == cblocks) {                                                                \
       ld_cb = 0;                                                                             \
@@ -175,46 +177,74 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) k_conv_fp8(Conv8Args a) {
     if (p < nk) YV1_ISSUE8(p);
 
   const int l31 = lane & 31, lh = lane >> 5;
-  int cur = 0, nxt = NST - 1;
-  for (int kt = 0; kt < nk; ++kt) {
+  // per-lane byte offsets of the fragment halves inside a stage, computed once: in the unrolled loop the stage base is an
+  // immediate.  A lane's 32 bytes of the 64-byte k-slab are chunks c0 and c0+1 (swizzled per row).
+  constexpr int KS8 = BKB / 64;
+  int fa_lo[TM][KS8], fa_hi[TM][KS8], fb_lo[TN][KS8], fb_hi[TN][KS8];
+#pragma unroll
+  for (int ks = 0; ks < KS8; ++ks) {
+    const int c0 = ks * 4 + lh * 2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (BM / WM) + i * 32 + l31;
+      fa_lo[i][ks] = row * BKB + swz8<CPR>(row, c0) * 16;
+      fa_hi[i][ks] = row * BKB + swz8<CPR>(row, c0 + 1) * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * (BN / WN) + j * 32 + l31;
+      fb_lo[j][ks] = A_BYTES + row * BKB + swz8<CPR>(row, c0) * 16;
+      fb_hi[j][ks] = A_BYTES + row * BKB + swz8<CPR>(row, c0 + 1) * 16;
+    }
+  }
+#define YV1_MFMA8(BASE_)                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < KS8; ++ks) {                                       \
+    i32x8 fa[TM], fb[TN];                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                         \
+      const u32x4 lo = *reinterpret_cast<const u32x4*>((BASE_) + fa_lo[i][ks]);              \
+      const u32x4 hi = *reinterpret_cast<const u32x4*>((BASE_) + fa_hi[i][ks]);              \
+      fa[i] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w}; \
+    }                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                         \
+      const u32x4 lo = *reinterpret_cast<const u32x4*>((BASE_) + fb_lo[j][ks]);              \
+      const u32x4 hi = *reinterpret_cast<const u32x4*>((BASE_) + fb_hi[j][ks]);              \
+      fb[j] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w}; \
+    }                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) /* cbsz = blgp = 0: e4m3 operands; both block scales E8M0 127 = 2^0 */ \
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, \
+                                                                    0x7f7f7f7f);             \
+  }
+
+  int kt = 0;
+  {                                                    // steady state, unrolled over the ring (constant stage indices)
+    const int n_main = nk - (NST - 1);
+    for (; kt + NST <= n_main; kt += NST) {
+#pragma unroll
+      for (int c = 0; c < NST; ++c) {
+        // fragment reads of the previous step complete (and are not scheduled below) the barrier: the DMA after it
+        // refills that stage.  s_barrier alone is no memory fence to the compiler (see conv.hip).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt8<(NST - 2) * LPS>();
+        __builtin_amdgcn_s_barrier();
+        YV1_ISSUE8((c + NST - 1) % NST);
+        YV1_MFMA8(smem + c * STAGE);
+      }
+    }
+  }
+  int cur = 0, nxt = NST - 1;                          // kt is a multiple of NST here
+  for (; kt < nk; ++kt) {
     const int younger = min(nk - 1 - kt, NST - 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (younger >= 1) wait_vmcnt8<LPS>();
     else wait_vmcnt8<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + NST - 1 < nk) YV1_ISSUE8(nxt);
-    const unsigned char* sa = smem + cur * STAGE;
-    const unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BKB / 64; ++ks) {
-      i32x8 fa[TM], fb[TN];
-      const int c0 = ks * 4 + lh * 2;       // this lane's 32 bytes of the 64-byte k-slab: chunks c0, c0+1
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (BM / WM) + i * 32 + l31;
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(sa + row * BKB + swz8<CPR>(row, c0) * 16);
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(sa + row * BKB + swz8<CPR>(row, c0 + 1) * 16);
-        fa[i] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * (BN / WN) + j * 32 + l31;
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(sb + row * BKB + swz8<CPR>(row, c0) * 16);
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(sb + row * BKB + swz8<CPR>(row, c0 + 1) * 16);
-        fb[j] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)   // cbsz = blgp = 0: e4m3 operands; both block scales E8M0 127 = 2^0
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
-                                                                      0x7f7f7f7f);
-    }
-    // fragment reads complete (and are not scheduled below) the next barrier: the DMA after it refills this stage.
-    // s_barrier alone is no memory fence to the compiler (see conv.hip).
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    YV1_MFMA8(smem + cur * STAGE);
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
+#undef YV1_MFMA8
   __syncthreads();
 
   // ---- epilogue 1: t = bf16(acc * alpha + beta), staged through LDS (layout and DPP pairing as in conv.hip)
