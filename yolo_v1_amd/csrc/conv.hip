@@ -130,11 +130,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     for (int j = 0; j < TN; ++j) {
       const int col = wn * (BN / WN) + j * 32 + l31;
       const int rbase = wm * (BM / WM) + i * 32 + 4 * lh;
+      const bool affine = a.escale != nullptr || a.erelu;   // training launches (raw conv output) skip scale/shift/clamp
       const float al = a.escale ? a.escale[n0 + col] : 1.f, be = a.escale ? a.eshift[n0 + col] : 0.f;
       const float lo_clamp = (a.erelu && !a.ERES) ? 0.f : -3.0e38f;     // ReLU here unless a residual is added first
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        const float mine_lo = fmaxf(acc[i][j][e] * al + be, lo_clamp), mine_hi = fmaxf(acc[i][j][e + 1] * al + be, lo_clamp);
+        const float mine_lo = affine ? fmaxf(acc[i][j][e] * al + be, lo_clamp) : acc[i][j][e];
+        const float mine_hi = affine ? fmaxf(acc[i][j][e + 1] * al + be, lo_clamp) : acc[i][j][e + 1];
         const float send = odd ? mine_lo : mine_hi;
         const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
         // even lane: row(e), channels (col, col+1) = (mine_lo, neighbour's acc[e]); odd: row(e+1), (col-1, col)

@@ -235,7 +235,7 @@ __device__ __forceinline__ void wg_wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((NW & 15) | ((NW >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
-template <int BT>
+template <int BT, bool LIN>
 __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
   constexpr int KP = 32, NST = 3;
   constexpr int ROWB = BT * 2;                         // bytes per pixel row of a tile
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_dma(WgradArgs a) {
   // Loader state.  dY rows are consecutive pixels: one pointer per piece, advanced by KP pixels per K-step.  The X rows
   // are too when the convolution has stride 1 (every 1x1 layer but the four projection shortcuts): `lin`; otherwise
   // the (n, p, q) state of the generic kernel is kept.  Rows past M read the zero page.
-  const bool lin = a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0;
+  constexpr bool lin = LIN;                            // host: a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0
   int mrow[PPW];
   const bf16_t* pa[PPW];
   const bf16_t* pb[PPW];
@@ -838,15 +838,19 @@ int run_plan(const Plan& p, WgradArgs& a, int nblocks, hipStream_t stream) {
     // measured: 5-12 % faster on the 1x1 layers, slower on the per-tap workgroups of 3x3 layers -> 1x1 only
     if (dma && a.R * a.S == 1 && p.kp == 32 && p.bmc == p.bnc && (p.bmc == 128 || p.bmc == 64) && a.Cout % p.bmc == 0 &&
         (a.Cin % p.bnc == 0 || (p.bmc == 128 && a.Cin % 8 == 0)) && a.lddy % 8 == 0 && a.ldx % 8 == 0) {
+      const bool lin = a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0;     // X rows are consecutive pixels too
       if (p.bmc == 128) {
         static bool once = false;
         if (!once) {
-          YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 32 * 256));
+          YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 32 * 256));
+          YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 32 * 256));
           once = true;
         }
-        hipLaunchKernelGGL(k_wgrad_dma<128>, dim3(nblocks), dim3(256), 3 * 2 * 32 * 256, stream, a);
+        if (lin) hipLaunchKernelGGL((k_wgrad_dma<128, true>), dim3(nblocks), dim3(256), 3 * 2 * 32 * 256, stream, a);
+        else hipLaunchKernelGGL((k_wgrad_dma<128, false>), dim3(nblocks), dim3(256), 3 * 2 * 32 * 256, stream, a);
       } else {
-        hipLaunchKernelGGL(k_wgrad_dma<64>, dim3(nblocks), dim3(256), 3 * 2 * 32 * 128, stream, a);
+        if (lin) hipLaunchKernelGGL((k_wgrad_dma<64, true>), dim3(nblocks), dim3(256), 3 * 2 * 32 * 128, stream, a);
+        else hipLaunchKernelGGL((k_wgrad_dma<64, false>), dim3(nblocks), dim3(256), 3 * 2 * 32 * 128, stream, a);
       }
       YV1_LAUNCH_CHECK();
       return YV1_OK;
