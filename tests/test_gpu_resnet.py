@@ -209,6 +209,35 @@ def test_training_trajectory_follows_the_oracle_over_several_sgd_steps():
     assert int(sd["layer3.2.bn2.num_batches_tracked"]) == steps
 
 
+def test_training_steps_are_bitwise_reproducible_run_to_run():
+    # No atomics, fixed-order split-K and partial-row reductions: two independent runs from the same initial state must
+    # agree bit for bit (loss sequence and every parameter).  Guards the raw-barrier DMA loops too: a missing LDS read
+    # fence once made the convolution results differ from run to run.
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    from yolo_v1_amd.optim import FusedSGD
+    from yolo_v1_amd.train import train_step
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    from oracle import train_step as ots
+    N, hw = 8, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, 3, hw, hw, generator=g).to(DEV)
+    _, tg = ots.synthetic_batch(N, hw // 64, hw=8)
+    tg = tg.to(DEV)
+    runs = []
+    for _ in range(3):
+        torch.manual_seed(4)
+        net = resnet50(S=7).to(DEV).train()
+        opt = FusedSGD(net.parameters(), lr=0.0, momentum=0.99)
+        crit = YOLOLossV1(N, hw // 64, 2, 20, _quiet=True)
+        losses = [train_step(net, crit, opt, x, tg, 1e-4).item() for _ in range(4)]
+        torch.cuda.synchronize()
+        runs.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    for losses, sd in runs[1:]:
+        assert losses == runs[0][0], (losses, runs[0][0])
+        for k, v in sd.items():
+            assert torch.equal(v, runs[0][1][k]), k
+
+
 def test_resnet50_every_layer_teacher_forced():
     """Each conv / BN+ReLU / block output of the HIP forward against fp32 torch math applied to the HIP
     path's own (bf16) input of that layer: isolates every kernel launch in the real network shapes."""
