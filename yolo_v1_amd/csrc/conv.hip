@@ -432,16 +432,24 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) 
   const int slot = tid % CPR, rrow = tid / CPR;
   const int lchunk = swz<BK>(rrow, slot);              // logical chunk this lane fetches (same key for every pass)
   int pix_base[A_PASSES], ph[A_PASSES], qw[A_PASSES];
+  // pointwise, unit stride, no padding (most launches): GEMM row m IS input pixel m -- no (n, p, q) decomposition (two
+  // integer divisions per pass); the row is addressed as pixel (0, m) of a one-row image that SET_TAP never clips
+  const bool direct = a.R * a.S == 1 && a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0 && a.log2d == 0 &&
+                      a.P == a.IH && a.Q == a.IW;
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int m = m0 + rrow + i * RPP;
     if (m < a.M) {
-      const int pq = a.P * a.Q;
-      const int n = m / pq, rem = m - n * pq;
-      const int p = rem / a.Q, q = rem - p * a.Q;
-      pix_base[i] = n * a.IH * a.IW;
-      ph[i] = p * a.ah + a.ch;
-      qw[i] = q * a.aw + a.cw;
+      if (direct) {
+        pix_base[i] = m; ph[i] = 0; qw[i] = 0;
+      } else {
+        const int pq = a.P * a.Q;
+        const int n = m / pq, rem = m - n * pq;
+        const int p = rem / a.Q, q = rem - p * a.Q;
+        pix_base[i] = n * a.IH * a.IW;
+        ph[i] = p * a.ah + a.ch;
+        qw[i] = q * a.aw + a.cw;
+      }
     } else {
       pix_base[i] = -1; ph[i] = 0; qw[i] = 0;
     }
