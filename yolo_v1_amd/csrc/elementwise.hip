@@ -437,15 +437,28 @@ __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restric
   k3[c] = a1 * sx / count;
 }
 
+__device__ __forceinline__ void bwd_apply_coeffs(const BwdArgs& a, int c8, float* k1, float* ka, float* kb) {
+  float mu[8], is[8], k2[8], k3[8];
+  load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
+  load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float t = is[k] * k3[k];
+    ka[k] = -t;
+    kb[k] = mu[k] * t - k2[k];
+  }
+}
+
 template <bool FIXED_C>                                  // see k_bn_apply: 10 (14) of 14 (18) memory instructions were these
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
   const int CH = a.C >> 3;
   const long long total = a.npix * CH;
-  float mu[8], is[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+  // dy = k1*g - k2 - (y - mean)*invstd*k3 = k1*g + ka*y + kb with ka = -invstd*k3, kb = mean*invstd*k3 - k2: two FMAs per
+  // value and three per-channel vectors live across the loop instead of five
+  float k1[8], ka[8], kb[8], sc[8], sh[8];
   if (FIXED_C) {
     const int c8 = (int)((blockIdx.x * 256u + threadIdx.x) % CH) * 8;
-    load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
-    load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+    bwd_apply_coeffs(a, c8, k1, ka, kb);
     if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
   }
   const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
@@ -460,13 +473,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
     if (FIXED_C) masked_grad(a, p, c8, yv, g, sc, sh);
     else masked_grad(a, p, c8, yv, g);
     if (a.dres) *reinterpret_cast<u32x4*>(a.dres + p * a.lddres + c8) = pack8(g);
-    if (!FIXED_C) {
-      load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
-      load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
-    }
+    if (!FIXED_C) bwd_apply_coeffs(a, c8, k1, ka, kb);
     float o[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = k1[k] * g[k] - k2[k] - (yv[k] - mu[k]) * is[k] * k3[k];
+    for (int k = 0; k < 8; ++k) o[k] = k1[k] * g[k] + (ka[k] * yv[k] + kb[k]);
     if (a.accumulate) {
       float old[8];
       unpack8(*reinterpret_cast<const u32x4*>(a.dy + p * a.lddy + c8), old);
@@ -554,11 +564,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_pool2(BwdArgs a) {
   // the grid stride is a multiple of CH when CH divides 256 (the stems: CH = 8): a thread then keeps its channel chunk
   // for the whole loop and the seven per-channel vectors are loaded once
   const bool fixed_c = (256 % CH) == 0;
-  float mu[8], is[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+  float k1[8], ka[8], kb[8], sc[8], sh[8];
   if (fixed_c) {
     const int c8 = (int)(threadIdx.x % CH) * 8;
-    load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
-    load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+    bwd_apply_coeffs(a, c8, k1, ka, kb);
     if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
   }
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -570,8 +579,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_pool2(BwdArgs a) {
     float g[4][8];
     pooled_patch_grad(a, n, pa, pb, c8, OH, OW, g);
     if (!fixed_c) {
-      load8f(a.mean + c8, mu); load8f(a.invstd + c8, is);
-      load8f(a.k1 + c8, k1); load8f(a.k2 + c8, k2); load8f(a.k3 + c8, k3);
+      bwd_apply_coeffs(a, c8, k1, ka, kb);
       if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
     }
 #pragma unroll
@@ -582,7 +590,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_pool2(BwdArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float gk = (a.mask_mode == 2 && !(yv[k] * sc[k] + sh[k] > 0.f)) ? 0.f : g[q][k];
-        o[k] = k1[k] * gk - k2[k] - (yv[k] - mu[k]) * is[k] * k3[k];
+        o[k] = k1[k] * gk + (ka[k] * yv[k] + kb[k]);
       }
       *reinterpret_cast<u32x4*>(a.dy + p * a.lddy + c8) = pack8(o);
     }
