@@ -210,6 +210,13 @@ int yv1_sgd_max_tensors(void);
 int yv1_sgd_momentum_step(float* const* w, const float* const* g, float* const* m, const long long* n, int count,
                           const float* lr, float momentum, float grad_scale, yv1_stream_t stream);
 
+/* ---- introspection (tests) ------------------------------------------------------------------------------------ */
+/* The kernel template(s) the most recent convolution / dgrad / wgrad entry point launched on the calling host thread,
+ * ';'-separated, e.g. "k_conv_dma<128,256,32,2,2,3> direct".  Copies at most cap-1 characters (NUL-terminated) and
+ * returns the full length.  buf is a HOST pointer.  The reference has no counterpart: cuDNN picks its algorithm
+ * silently behind nn.Conv2d (OriginResNet.py:21-29); here the parity tests assert which tile they covered. */
+int yv1_last_config(char* buf, int cap);
+
 #ifdef __cplusplus
 }
 #endif

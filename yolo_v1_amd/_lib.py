@@ -87,6 +87,8 @@ SIGNATURES = {
     "yv1_prep_weights_multi": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "yv1_prep_stem_weights": (c_i, [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p, c_p]),
     "yv1_unpack_stem_grad": (c_i, [c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p]),
+    # cfglog.hip
+    "yv1_last_config": (c_i, [ctypes.c_char_p, c_i]),
     # optim.hip
     "yv1_sgd_max_tensors": (c_i, []),
     "yv1_sgd_momentum_step": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_f, c_f, c_p]),
@@ -112,6 +114,13 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def last_config():
+    """The kernel templates the last conv / dgrad / wgrad call of this thread launched (list of names)."""
+    buf = ctypes.create_string_buffer(512)
+    lib().yv1_last_config(buf, 512)
+    return [c for c in buf.value.decode().split(";") if c]
 
 
 def stream_ptr(device=None):

@@ -25,6 +25,7 @@ SOURCES = {
     "wgrad.hip": [],
     "elementwise.hip": [],
     "optim.hip": [],
+    "cfglog.hip": [],
 }
 
 

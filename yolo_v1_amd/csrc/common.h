@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define YV1_OK 0
 #define YV1_ERR_BAD_ARG 1001
@@ -19,6 +20,25 @@
     hipError_t e__ = (call);                       \
     if (e__ != hipSuccess) return (int)e__;        \
   } while (0)
+
+// Raises a kernel's dynamic-LDS limit once PER DEVICE (the attribute is per device, a process may drive several) and
+// thread-safely: one bit per device ordinal in an atomic latch that belongs to the expansion site (= one kernel
+// instantiation).  Two threads racing here both set the same value, which is harmless.
+#define YV1_SET_MAX_LDS(kern, bytes)                                                                              \
+  do {                                                                                                            \
+    static std::atomic<unsigned long long> done__{0ull};                                                          \
+    int dev__ = 0;                                                                                                \
+    YV1_HIP(hipGetDevice(&dev__));                                                                                \
+    const unsigned long long bit__ = 1ull << (dev__ & 63);                                                        \
+    if (!(done__.load(std::memory_order_acquire) & bit__)) {                                                      \
+      YV1_HIP(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      done__.fetch_or(bit__, std::memory_order_release);                                                          \
+    }                                                                                                             \
+  } while (0)
+
+// dispatch record (cfglog.hip): every convolution entry point resets it, every kernel launch appends its template name
+void yv1_cfg_reset();
+void yv1_cfg_note(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 

@@ -571,13 +571,15 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) 
   for (; kt < nk; ++kt) {
     // retire K-step kt: the younger in-flight steps (at most NST-2 of them) may stay outstanding
     const int younger = min(nk - 1 - kt, NST - 2);
+    // fragment reads of the previous step (the last steady-state step or the previous tail step) complete BEFORE the
+    // barrier after which stage nxt is refilled -- same fence, same place as in the steady state above
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (younger >= 2) wait_vmcnt<2 * LPS>();
     else if (younger == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                      // everyone's pieces of step kt landed; everyone left stage nxt
     if (kt + NST - 1 < nk && !(a.dbg & 1)) YV1_ISSUE(nxt);
     if (!(a.dbg & 2)) YV1_MFMA_BLOCK(smem + cur * STAGE);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads complete before the next barrier (see above)
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
@@ -597,12 +599,11 @@ int launch_dma(ConvArgs& a, hipStream_t stream) {
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
   auto kern = k_conv_dma<BM, BN, BK, WM, WN, NST>;
-  if (LDS > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-      once = true;
-    }
+  if (LDS > 64 * 1024) YV1_SET_MAX_LDS(kern, LDS);
+  {
+    const bool direct = a.R * a.S == 1 && a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0 && a.log2d == 0 &&
+                        a.P == a.IH && a.Q == a.IW;         // the kernel's own condition for its direct addressing
+    yv1_cfg_note("k_conv_dma<%d,%d,%d,%d,%d,%d>%s", BM, BN, BK, WM, WN, NST, direct ? " direct" : "");
   }
   hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), LDS, stream, a);
   YV1_LAUNCH_CHECK();
@@ -623,13 +624,8 @@ int launch(ConvArgs& a, hipStream_t stream) {
   const size_t lds = stage_bytes > (size_t)EPI ? stage_bytes : (size_t)EPI;
   auto kern = k_conv_gemm<BM, BN, BK, WM, WN>;
   constexpr size_t MAXLDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-  if (MAXLDS > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAXLDS));
-      once = true;
-    }
-  }
+  if (MAXLDS > 64 * 1024) YV1_SET_MAX_LDS(kern, MAXLDS);
+  yv1_cfg_note("k_conv_gemm<%d,%d,%d,%d,%d>", BM, BN, BK, WM, WN);
   hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), lds, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
@@ -753,6 +749,7 @@ __global__ void k_pack_input(const float* __restrict__ x, bf16_t* __restrict__ y
 extern "C" int yv1_conv2d_fwd_nhwc_bf16(const void* x, const void* w, void* y, int N, int IH, int IW, int ldx, int Cin,
                                         int Cout, int ldy, int k, int stride, int pad, float* stats,
                                         hipStream_t stream) {
+  yv1_cfg_reset();
   if (!x || !w || !y || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   ConvArgs a;
   a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
@@ -775,6 +772,7 @@ extern "C" int yv1_conv2d_fwd_bn_act_nhwc_bf16(const void* x, const void* w, voi
                                                int Cout, int ldy, int k, int stride, int pad, const float* scale,
                                                const float* shift, const void* residual, int ldres, int relu,
                                                hipStream_t stream) {
+  yv1_cfg_reset();
   if (!x || !w || !y || !scale || !shift || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   if (residual && ldres % 8) return YV1_ERR_UNSUPPORTED;
   ConvArgs a;
@@ -795,6 +793,7 @@ extern "C" int yv1_conv2d_fwd_bn_act_nhwc_bf16(const void* x, const void* w, voi
 // xp: [N][H+6][W+6][4] bf16; w: [Cout][7][32] bf16 (element s*4+c of row r; zero for c==3 and s==7).
 static int stem_forward(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy, float* stats,
                         const float* scale, const float* shift, int relu, hipStream_t stream) {
+  yv1_cfg_reset();
   if (!xp || !w || !y || N <= 0 || (H & 1) || (W & 1)) return YV1_ERR_BAD_ARG;
   ConvArgs a;
   a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
@@ -833,6 +832,7 @@ extern "C" int yv1_conv2d_stem_fwd_bn_act_bf16(const void* xp, const void* w, vo
 extern "C" int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx,
                                           int Cin, int Cout, int lddy, int k, int stride, int pad, int accumulate,
                                           hipStream_t stream) {
+  yv1_cfg_reset();
   if (!dy || !wt || !dx || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   if (stride != 1 && stride != 2) return YV1_ERR_UNSUPPORTED;
   const int OH = (IH + 2 * pad - k) / stride + 1, OW = (IW + 2 * pad - k) / stride + 1;
@@ -883,6 +883,7 @@ extern "C" int yv1_conv2d_dgrad_nhwc_bf16(const void* dy, const void* wt, void* 
 extern "C" int yv1_conv2d_dgrad_add_masked_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW,
                                                      int lddx, int Cin, int Cout, int lddy, const void* g, int ldg,
                                                      const void* relu_mask, int ldmask, hipStream_t stream) {
+  yv1_cfg_reset();
   if (!dy || !wt || !dx || !g || !relu_mask || N <= 0) return YV1_ERR_BAD_ARG;
   if (ldg % 8 || Cin % 8) return YV1_ERR_UNSUPPORTED;
   ConvArgs a;

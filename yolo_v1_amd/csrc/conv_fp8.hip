@@ -358,13 +358,8 @@ int launch8(Conv8Args& a, hipStream_t stream) {
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
   auto kern = k_conv_fp8<BM, BN, BKB, WM, WN, NST>;
-  if (LDS > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      YV1_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-      once = true;
-    }
-  }
+  if (LDS > 64 * 1024) YV1_SET_MAX_LDS(kern, LDS);
+  yv1_cfg_note("k_conv_fp8<%d,%d,%d,%d,%d,%d>", BM, BN, BKB, WM, WN, NST);
   hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), LDS, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
@@ -516,6 +511,7 @@ extern "C" int yv1_conv2d_fwd_nhwc_fp8(const void* x8, const void* w8, const flo
                                        const void* residual, int ldr, void* y_bf16, int ld16, void* y_fp8, int ld8, int N,
                                        int IH, int IW, int ldx, int Cin, int Cout, int k, int stride, int pad, int relu,
                                        yv1_stream_t stream) {
+  yv1_cfg_reset();
   if (!x8 || !w8 || !alpha || !beta || (!y_bf16 && !y_fp8) || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   if (Cin % 64 || Cout % 64 || ldx % 16) return YV1_ERR_UNSUPPORTED;
   if ((y_bf16 && ld16 % 8) || (y_fp8 && ld8 % 8) || (residual && ldr % 8)) return YV1_ERR_UNSUPPORTED;
@@ -557,6 +553,7 @@ extern "C" int yv1_conv2d_fp8_stats_rows(int M, int Cout) {
 extern "C" int yv1_conv2d_fwd_stats_nhwc_fp8(const void* x8, const void* w8, const float* alpha, const float* zero_beta,
                                              void* y, int ldy, float* stats, int N, int IH, int IW, int ldx, int Cin,
                                              int Cout, int k, int stride, int pad, yv1_stream_t stream) {
+  yv1_cfg_reset();
   if (!x8 || !w8 || !alpha || !zero_beta || !y || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   if (Cin % 64 || Cout % 64 || ldx % 16 || ldy % 8) return YV1_ERR_UNSUPPORTED;
   Conv8Args a;

@@ -747,13 +747,8 @@ Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int 
 template <int KP, int BMC, int BNC>
 int launch3(W3Args& a, int nblocks, hipStream_t stream) {
   constexpr int STAGE = KP * (BMC == 32 ? 64 : BMC * 2 + 64) + 3 * (KP + 2) * (BNC * 2 + 64);
-  if (2 * STAGE > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3<KP, BMC, BNC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
-      once = true;
-    }
-  }
+  if (2 * STAGE > 64 * 1024) YV1_SET_MAX_LDS((k_wgrad3x3<KP, BMC, BNC>), 2 * STAGE);
+  yv1_cfg_note("k_wgrad3x3<%d,%d,%d>", KP, BMC, BNC);
   hipLaunchKernelGGL((k_wgrad3x3<KP, BMC, BNC>), dim3(nblocks), dim3(256), 2 * STAGE, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
@@ -762,13 +757,8 @@ int launch3(W3Args& a, int nblocks, hipStream_t stream) {
 template <int BMC, int BNC, int WM, int WN, int KP>
 int launch(WgradArgs& a, int nblocks, hipStream_t stream) {
   constexpr int STAGE = KP * (BMC == 32 ? 64 : BMC * 2 + 64) + KP * (BNC == 32 ? 64 : BNC * 2 + 64);
-  if (2 * STAGE > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad<BMC, BNC, WM, WN, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
-      once = true;
-    }
-  }
+  if (2 * STAGE > 64 * 1024) YV1_SET_MAX_LDS((k_wgrad<BMC, BNC, WM, WN, KP>), 2 * STAGE);
+  yv1_cfg_note("k_wgrad<%d,%d,%d,%d,%d>", BMC, BNC, WM, WN, KP);
   hipLaunchKernelGGL((k_wgrad<BMC, BNC, WM, WN, KP>), dim3(nblocks), dim3(256), 2 * STAGE, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
@@ -839,13 +829,10 @@ int run_plan(const Plan& p, WgradArgs& a, int nblocks, hipStream_t stream) {
     if (dma && a.R * a.S == 1 && p.kp == 32 && p.bmc == p.bnc && (p.bmc == 128 || p.bmc == 64) && a.Cout % p.bmc == 0 &&
         (a.Cin % p.bnc == 0 || (p.bmc == 128 && a.Cin % 8 == 0)) && a.lddy % 8 == 0 && a.ldx % 8 == 0) {
       const bool lin = a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0;     // X rows are consecutive pixels too
+      yv1_cfg_note("k_wgrad_dma<%d,%s>", p.bmc, lin ? "true" : "false");
       if (p.bmc == 128) {
-        static bool once = false;
-        if (!once) {
-          YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 32 * 256));
-          YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 32 * 256));
-          once = true;
-        }
+        YV1_SET_MAX_LDS((k_wgrad_dma<128, true>), 3 * 2 * 32 * 256);
+        YV1_SET_MAX_LDS((k_wgrad_dma<128, false>), 3 * 2 * 32 * 256);
         if (lin) hipLaunchKernelGGL((k_wgrad_dma<128, true>), dim3(nblocks), dim3(256), 3 * 2 * 32 * 256, stream, a);
         else hipLaunchKernelGGL((k_wgrad_dma<128, false>), dim3(nblocks), dim3(256), 3 * 2 * 32 * 256, stream, a);
       } else {
@@ -881,6 +868,7 @@ extern "C" size_t yv1_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Ci
 extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx,
                                           int Cin, int Cout, int lddy, int k, int stride, int pad, void* workspace,
                                           size_t workspace_bytes, hipStream_t stream) {
+  yv1_cfg_reset();
   if (!x || !dy || !dw || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   if (Cin % 32 || ldx % 8 || lddy % 8 || Cout % 8) return YV1_ERR_UNSUPPORTED;
   WgradArgs a;
@@ -902,6 +890,7 @@ extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     const int rc3 = p3.bmc == 64 ? launch3<32, 64, 64>(w, nb, stream) : launch3<32, 32, 128>(w, nb, stream);
     if (rc3) return rc3;
     const long long n3 = (long long)Cout * 9 * Cin;
+    yv1_cfg_note("k_reduce_slabs splitK=%d", p3.splitK);
     hipLaunchKernelGGL(k_reduce_slabs, dim3((int)((n3 / 4 + 15) / 16)), dim3(256), 0, stream, (const float*)workspace, dw,
                        n3, p3.splitK);
     YV1_LAUNCH_CHECK();
@@ -918,6 +907,7 @@ extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
   if (p.splitK > 1) {
     const long long n = (long long)Cout * k * k * Cin;
     const int blocks = (int)((n / 4 + 15) / 16);
+    yv1_cfg_note("k_reduce_slabs splitK=%d", p.splitK);
     hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, p.splitK);
     YV1_LAUNCH_CHECK();
   }
@@ -944,6 +934,7 @@ extern "C" size_t yv1_conv2d_stem_wgrad_workspace_bytes(int N, int H, int W, int
 
 extern "C" int yv1_conv2d_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int N, int H, int W, int Cout,
                                           int lddy, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  yv1_cfg_reset();
   if (!xp || !dy || !dw || !workspace || N <= 0 || (H & 1) || (W & 1)) return YV1_ERR_BAD_ARG;
   if (Cout != 64 || lddy % 8) return YV1_ERR_UNSUPPORTED;
   StemWgradArgs a;
@@ -953,11 +944,8 @@ extern "C" int yv1_conv2d_stem_wgrad_bf16(const void* xp, const void* dy, float*
   const int splits = stem_plan(a.M, &a.steps_per_split);
   if ((size_t)splits * 64 * 224 * sizeof(float) > workspace_bytes) return YV1_ERR_WORKSPACE;
   constexpr int STAGE = 32 * (64 * 2 + 64) + 7 * 32 * (32 * 2);
-  static bool once = false;
-  if (!once) {
-    YV1_HIP(hipFuncSetAttribute((const void*)k_wgrad_stem, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
-    once = true;
-  }
+  YV1_SET_MAX_LDS(k_wgrad_stem, 2 * STAGE);
+  yv1_cfg_note("k_wgrad_stem");
   hipLaunchKernelGGL(k_wgrad_stem, dim3(splits), dim3(256), 2 * STAGE, stream, a);
   YV1_LAUNCH_CHECK();
   const long long n = 64ll * 7 * 32;
