@@ -26,17 +26,40 @@ TRAIN_GFLOP_PER_IMG = {("resnet", 7): 103.25, ("resnet", 14): 97.22, ("densenet"
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def source_fingerprint():
+    """sha1 over the kernel sources and the launch sequences (csrc/*, backbones/*.py, ops.py, engine.py): what decides
+    the HBM traffic of a step.  tools/pmc_traffic.py stores it with the measurement."""
+    import hashlib
+    h = hashlib.sha1()
+    pk = os.path.join(ROOT, "yolo_v1_amd")
+    files = [os.path.join(pk, "csrc", f) for f in sorted(os.listdir(os.path.join(pk, "csrc")))]
+    files += [os.path.join(pk, "backbones", f) for f in sorted(os.listdir(os.path.join(pk, "backbones"))) if f.endswith(".py")]
+    files += [os.path.join(pk, "ops.py"), os.path.join(pk, "engine.py")]
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(backbone, S, batch):
-    """HBM bytes per step from the PMC passes committed under profiles/ (tools/pmc_traffic.py); None when the
-    committed measurement is for a different workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        t = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if t.get("workload") != "%s S=%d batch %d" % (backbone, S, batch):
-        return None
-    return t.get("hbm_bytes_per_step")
+    """HBM bytes per step from the PMC passes committed under profiles/ (tools/pmc_traffic.py).  Returns
+    (bytes or None, provenance dict): the value is refused (None) when the committed measurement is for another
+    workload or was taken with different kernel sources than the ones running now."""
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+    for name in reversed(cands):                      # newest round first
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if t.get("workload") != "%s S=%d batch %d" % (backbone, S, batch):
+            continue
+        prov = {"file": "profiles/" + name, "measured_at_source": t.get("source_fingerprint"),
+                "current_source": source_fingerprint()}
+        if prov["measured_at_source"] != prov["current_source"]:
+            prov["stale_value"] = t.get("hbm_bytes_per_step")
+            prov["note"] = "refused: kernel sources changed since the PMC passes were taken"
+            return None, prov
+        return t.get("hbm_bytes_per_step"), prov
+    return None, {"note": "no PMC measurement committed for this workload"}
 
 
 def cpu_baseline(steps=60, warmup=3):
@@ -149,6 +172,107 @@ def host_input_rate(graphed, step, images, target, steps):
             "one batch ahead; PCIe-inclusive, informative only"}
 
 
+def other_training_config(backbone, S, batch, device, fp8_forward=False, steps=8, warmup=3):
+    """One more BASELINE.json configuration in the same process, after the headline timed region: the same step
+    (forward + loss + backward + fused SGD, hipGraph replay) for another backbone / grid, timed with HIP events on the
+    launch stream.  Reported under ``other_configs`` -- never in ``value``."""
+    from yolo_v1_amd.train import GraphedStep, build
+    from yolo_v1_amd.utils.YOLODataLoader import synthetic_batch
+    torch.manual_seed(0)
+    net, loss_layer, opt = build(backbone, S, 2, 20, batch, device, quiet=True, fused_optimizer=True)
+    if fp8_forward:
+        net.fp8_forward = True
+    images, target = synthetic_batch(batch, S, seed=1234, device=device)
+    for g in opt.param_groups:
+        g['lr'] = 1e-6
+    graphed = GraphedStep(net, loss_layer, opt, images, target, None, warmup=warmup)
+    it = graphed.steps_done
+    for _ in range(2):
+        it += 1
+        graphed(it * 1e-6)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        it += 1
+        loss = graphed(it * 1e-6)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    gflop = TRAIN_GFLOP_PER_IMG[(backbone, S)]
+    tf = batch * gflop / ms                      # GFLOP / ms = TFLOP/s
+    peak = PEAK_BF16_TFLOPS
+    out = {"workload": "%s 448x448 S=%d B=2 C=20, per-GPU batch %d, fwd+loss+bwd+SGD, hipGraph replay"
+                       % ("ResNet-50" if backbone == "resnet" else "DenseNet-121", S, batch),
+           "dtype": "fp8-e4m3 forward GEMMs, bf16 backward" if fp8_forward else "bf16",
+           "value": round(batch / ms * 1e3, 1), "unit": "images/sec", "ms_per_step": round(ms, 3), "steps": steps,
+           "achieved_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 5)}
+    del graphed, net, opt, loss_layer
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_eval_config(S, batch, device, iters=10):
+    """BASELINE config 5's evaluation leg: eval-mode ResNet-50 forward + batched decoder/NMS (utils/utils.py:389-418 as
+    one batch), bf16 fused-epilogue path and the fp8 e4m3 executor, hipGraph replay."""
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    from yolo_v1_amd.infer_fp8 import ResNetFp8
+    from yolo_v1_amd.utils.utils import decode_batch
+    torch.manual_seed(0)
+    net = resnet50(S=S).to(device).eval()
+    x = torch.randn(batch, 3, 448, 448, device=device)
+    eng = ResNetFp8(net)
+    res = {}
+    for name, fwd in (("bf16", lambda: net(x)), ("fp8_e4m3", lambda: eng(x))):
+        def fn():
+            with torch.no_grad():
+                return decode_batch(fwd(), grid_num=S, B=2, thresh=0.005, nms_th=0.45)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        res[name] = {"value": round(batch / ms * 1e3, 1), "unit": "images/sec", "ms_per_batch": round(ms, 3)}
+        del g
+    res["workload"] = "ResNet-50 448x448 S=%d eval-mode forward + batched decoder/NMS, batch %d, hipGraph replay" % (S, batch)
+    del eng, net
+    torch.cuda.empty_cache()
+    return res
+
+
+def self_launch(nproc, argv=None):
+    """Runs this script as ``nproc`` ranks under torch.distributed.run (one process per GPU, RCCL rendezvous on
+    127.0.0.1, a free port) as a CHILD process and returns its exit code.  The children inherit stdout/stderr, so rank 0's
+    JSON line is the only line on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,12 +288,19 @@ def main():
     ap.add_argument("--host-input", type=int, default=1,
                     help="after the timed region, also time the same steps fed from pinned host memory (fp32 batch per "
                          "step over PCIe, copy stream, one batch ahead) and report it as host_input -- never as value")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="after the headline timed region also time BASELINE configs 3 and 5 (DenseNet-121 S=7, ResNet-50 "
+                         "S=14 bf16 / fp8-forward training, S=14 eval + batched NMS) and report them under other_configs")
     ap.add_argument("--fused-sgd", type=int, default=1)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     ap.add_argument("--fp8-forward", action="store_true",
                     help="BASELINE config 5: forward convolutions on the fp8 (e4m3) MFMA path, bf16 backward (ResNet only; "
                          "NOT the headline configuration, which computes in bf16)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start N fresh ranks (one per GPU) BEFORE this process has touched the GPU -- no
+        # torch.cuda call, no libyv1 load so far -- relay their output and exit with their code.  Never exec.
+        raise SystemExit(self_launch(args.gpus))
 
     from yolo_v1_amd import distributed as ydist
     from yolo_v1_amd import _lib
@@ -245,7 +376,8 @@ def main():
         gflop = TRAIN_GFLOP_PER_IMG[(args.backbone, args.S)]
         step_s_dev = dev_ms / 1e3 / args.steps
         achieved = args.batch * gflop / 1e3 / step_s_dev          # TFLOP/s on one GPU, device time of the step
-        traffic = measured_traffic(args.backbone, args.S, args.batch) if not args.fp8_forward else None
+        traffic, traffic_prov = (measured_traffic(args.backbone, args.S, args.batch) if not args.fp8_forward
+                                 else (None, {"note": "fp8 forward: not measured"}))
         out = {
             "metric": "images/sec training (ResNet-50 448^2, S=7)" if args.backbone == "resnet" and args.S == 7
             else "images/sec training (%s 448^2, S=%d)" % (args.backbone, args.S),
@@ -261,7 +393,7 @@ def main():
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager launches"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_provenance": traffic_prov,
                          # informative: the same step against the HBM roofline (PMC bytes / device time, 8 TB/s peak)
                          "hbm_GBps": round(traffic / step_s_dev / 1e9, 1) if traffic else None,
                          "hbm_frac": round(traffic / step_s_dev / 8e12, 4) if traffic else None,
@@ -273,6 +405,24 @@ def main():
             out["host_input"] = host_input_rate(graphed, step, images, target, args.steps)
         if world == 1 and args.kernel_roofline and args.backbone == "resnet" and args.S == 7 and not args.fp8_forward:
             out["roofline"]["dominant_kernel"] = conv_kernel_roofline(args.batch, device)
+        headline = args.backbone == "resnet" and args.S == 7 and not args.fp8_forward
+        if world == 1 and args.other_configs and headline and graphed is not None:
+            # BASELINE.json configs 3 and 5 in the same run (driver-visible), after the headline timed region
+            del graphed
+            torch.cuda.empty_cache()
+            oc = {}
+            for key, kw in (("densenet121_S7", dict(backbone="densenet", S=7)),
+                            ("resnet50_S14", dict(backbone="resnet", S=14)),
+                            ("resnet50_S14_fp8_forward", dict(backbone="resnet", S=14, fp8_forward=True))):
+                try:
+                    oc[key] = other_training_config(batch=args.batch, device=device, **kw)
+                except Exception as e:                     # an auxiliary measurement must not take the headline line down
+                    oc[key] = {"error": repr(e)}
+            try:
+                oc["resnet50_S14_eval_nms"] = other_eval_config(14, args.batch, device)
+            except Exception as e:
+                oc["resnet50_S14_eval_nms"] = {"error": repr(e)}
+            out["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -189,3 +189,212 @@ def test_list_file_dataset_with_pil_loader(tmp_path):
     raw = yoloDataset(str(lst), train=False, S=7, raw_targets=True)
     imgs, boxes, labels, counts = collate_raw([raw[0], raw[1]])
     assert counts.tolist() == [2, 1] and labels[1, 0].item() == 7 and tuple(imgs.shape) == (2, 3, 448, 448)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# world-size-2 gloo tests of the data-parallel HOST logic around the training step (ADVICE high):
+# replicas made identical before the first step, and the train_step / GraphedStep sequencing (gradient-ready hooks from
+# inside the backward executor, phase boundary, start -> reduce_all -> optimizer) on a stub backbone whose executors are
+# plain torch-CPU code with the HipBackbone interface.
+def _spawn2(target, *extra):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() * 7 + len(extra)) % 500
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + extra) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def _sync_replicas_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yolo_v1_amd import ops
+    from yolo_v1_amd.backbones.OriginDenseNet import densenet121
+    from yolo_v1_amd.train import sync_replicas
+    torch.manual_seed(100 + rank)                     # what separate processes get: different initial weights
+    net = densenet121(S=14)
+    with torch.no_grad():
+        for b in net.buffers():
+            if b.dtype.is_floating_point:
+                b.add_(float(rank))
+            else:
+                b.add_(rank * 3)
+    import hashlib
+    digest = lambda: {k: hashlib.sha1(v.contiguous().numpy().tobytes()).hexdigest() for k, v in net.state_dict().items()}
+    before = digest()                                 # digests, not tensors: 700+ tensors through an mp.Queue stall
+    epoch0 = ops._WEIGHT_EPOCH[0]
+    sync_replicas(net)
+    after = digest()
+    q.put((rank, before, after, ops._WEIGHT_EPOCH[0] - epoch0))
+    dist.destroy_process_group()
+
+
+def test_sync_replicas_gloo_world2_makes_every_rank_equal_to_rank0():
+    (_, b0, a0, e0), (_, b1, a1, e1) = _spawn2(_sync_replicas_worker)
+    assert sum(b0[k] != b1[k] for k in b0) > 300                   # the ranks really started apart
+    for k in b0:
+        assert a0[k] == b0[k], k                                   # rank 0 unchanged
+        assert a1[k] == b0[k], k                                   # rank 1 == rank 0, parameters and BatchNorm buffers
+    assert e0 >= 1 and e1 >= 1                                     # bf16 weight shadows were invalidated
+
+
+def _make_stub_net():
+    import torch.nn as nn
+    from yolo_v1_amd.engine import HipBackbone
+
+    class StubFn(torch.autograd.Function):                        # engine.BackboneFn without the CUDA requirement
+        @staticmethod
+        def forward(ctx, net, x, *params):
+            with torch.no_grad():
+                pred, saved = net._run_forward(x, True, True)
+            ctx.net, ctx.saved, ctx.params = net, saved, params
+            return pred
+
+        @staticmethod
+        def backward(ctx, gpred):
+            with torch.no_grad():
+                grads = ctx.net._run_backward(ctx.saved, gpred)
+            return (None, None) + tuple(grads.get(p) for p in ctx.params)
+
+    class Stub(HipBackbone):
+        """pred = (tanh(x @ w1) @ w_l4) @ w3: three 'layers'; layer4 is where the executor calls the phase boundary."""
+
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(0)
+            self.w1 = nn.Parameter(torch.randn(12, 16, generator=g) * 0.3)
+            self.layer4 = nn.ParameterList([nn.Parameter(torch.randn(16, 16, generator=g) * 0.3)])
+            self.w3 = nn.Parameter(torch.randn(16, 5, generator=g) * 0.3)
+            self.emitted = []
+
+        def forward(self, x):
+            return StubFn.apply(self, x, *list(self.parameters()))
+
+        def _run_forward(self, x, train, save):
+            h1 = torch.tanh(x @ self.w1)
+            h2 = h1 @ self.layer4[0]
+            return h2 @ self.w3, (x, h1, h2)
+
+        def _run_backward(self, rec, gpred):
+            x, h1, h2 = rec
+            grads = {self.w3: h2.t() @ gpred}
+            self._emit(grads, [self.w3])
+            gh2 = gpred @ self.w3.t()
+            grads[self.layer4[0]] = h1.t() @ gh2
+            self._emit(grads, [self.layer4[0]])
+            if self._phase_boundary is not None:
+                self._phase_boundary(grads)
+            gh1 = (gh2 @ self.layer4[0].t()) * (1 - h1 * h1)
+            grads[self.w1] = x.t() @ gh1
+            self._emit(grads, [self.w1])
+            return grads
+    return Stub()
+
+
+class _StubLoss:
+    quiet = True
+
+    def __call__(self, pred, target):
+        return ((pred - target) ** 2).sum() / pred.shape[0]
+
+    def loss_and_grad(self, pred, target):
+        return ((pred - target) ** 2).sum() / pred.shape[0], 2.0 * (pred - target) / pred.shape[0]
+
+
+def _train_seq_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yolo_v1_amd.distributed import GradSync
+    from yolo_v1_amd.train import GraphedStep, sync_replicas, train_step
+    g = torch.Generator().manual_seed(50 + rank)                  # each rank its own shard of the batch
+    x, t = torch.randn(6, 12, generator=g), torch.randn(6, 5, generator=g)
+    out = {}
+    # (a) eager train_step: buckets issued from inside the backward executor through the gradient-ready hook
+    net = _make_stub_net()
+    with torch.no_grad():
+        net.w1.add_(0.01 * rank)                                  # replicas start apart ...
+    sync_replicas(net)                                            # ... and are made equal, as train.main does
+    opt = torch.optim.SGD(net.parameters(), lr=0.0, momentum=0.99)
+    sync = GradSync(net, bucket_mb=1e-4)                          # tiny buckets: one collective per layer, mid-backward
+    losses = [float(train_step(net, _StubLoss(), opt, x, t, 0.05, sync)) for _ in range(3)]
+    out["eager"] = ([p.detach().clone() for p in net.parameters()], losses, sync.buckets_issued)
+    # (b) the GraphedStep multi-rank sequence (phase boundary -> start(early) -> rest -> optimizer), executors driven
+    # directly; the two "replays" run the direct path eagerly (hipGraph capture itself needs the GPU)
+    net2 = _make_stub_net()
+    opt2 = torch.optim.SGD(net2.parameters(), lr=0.05, momentum=0.99)
+    gs = GraphedStep.__new__(GraphedStep)
+    gs.net, gs.loss_layer, gs.opt, gs.sync = net2, _StubLoss(), opt2, GradSync(None)
+    gs.images, gs.target, gs.two_phase, gs.in_graph_step, gs.phase1, gs.steps_done = x, t, True, False, None, 0
+
+    def replay1():
+        gs.phase1 = None
+        gs.loss = gs._direct(lambda grads: setattr(gs, "phase1", list(grads.items())))
+    for _ in range(3):
+        gs._dp_sequence(replay1, lambda: None)
+    out["graphed"] = ([p.detach().clone() for p in net2.parameters()], [id(p) for p, _ in gs.phase1] ==
+                      [id(net2.w3), id(net2.layer4[0])], gs.sync.buckets_issued)
+    tonp = lambda ts: [v.numpy().copy() for v in ts]
+    out["eager"] = (tonp(out["eager"][0]),) + out["eager"][1:]
+    out["graphed"] = (tonp(out["graphed"][0]),) + out["graphed"][1:]
+    q.put((rank, out, x.numpy().copy(), t.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_train_step_and_graphed_sequence_gloo_world2_match_global_batch_sgd():
+    (_, o0, x0, t0), (_, o1, x1, t1) = _spawn2(_train_seq_worker)
+    x0, t0, x1, t1 = (torch.from_numpy(v) for v in (x0, t0, x1, t1))
+    for o in (o0, o1):
+        o["eager"] = ([torch.from_numpy(v) for v in o["eager"][0]],) + o["eager"][1:]
+        o["graphed"] = ([torch.from_numpy(v) for v in o["graphed"][0]],) + o["graphed"][1:]
+    # single-process reference: the same three SGD steps on the mean of the two ranks' losses (== averaged gradients)
+    ref = _make_stub_net()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.99)
+    crit = _StubLoss()
+    for _ in range(3):
+        opt.zero_grad()
+        loss = 0.5 * (crit(ref._run_forward(x0, True, True)[0], t0) + crit(ref._run_forward(x1, True, True)[0], t1))
+        w = list(ref.parameters())
+        pred0, rec0 = ref._run_forward(x0, True, True)
+        pred1, rec1 = ref._run_forward(x1, True, True)
+        g0 = ref._run_backward(rec0, crit.loss_and_grad(pred0, t0)[1])
+        g1 = ref._run_backward(rec1, crit.loss_and_grad(pred1, t1)[1])
+        for p in w:
+            p.grad = 0.5 * (g0[p] + g1[p])
+        opt.step()
+    want = [p.detach() for p in ref.parameters()]
+    for o in (o0, o1):
+        for got, w in zip(o["eager"][0], want):
+            torch.testing.assert_close(got, w, rtol=1e-5, atol=1e-6)
+        for got, w in zip(o["graphed"][0], want):
+            torch.testing.assert_close(got, w, rtol=1e-5, atol=1e-6)
+        assert o["eager"][2] >= 3 * 3            # one bucket per layer and step, issued mid-backward
+        assert o["graphed"][1]                   # the phase boundary handed over exactly the deep layers' gradients
+        assert o["graphed"][2] == 3 * 2          # per step: one early collective + one for the rest
+    for a, b in zip(o0["eager"][0], o1["eager"][0]):
+        assert torch.equal(a, b)                 # replicas stay bit-identical
+    for a, b in zip(o0["graphed"][0], o1["graphed"][0]):
+        assert torch.equal(a, b)
+
+
+def test_bench_self_launches_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 2` must start its own ranks.  Without a GPU each rank stops at the
+    'needs a GPU' check -- which proves both that two ranks were started under torch.distributed.run and that the
+    parent got that far without any CUDA call -- and the parent relays the failure as its exit code."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "launch with torch.distributed.run" not in r.stderr
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]

@@ -79,6 +79,84 @@ class DenseNet(HipBackbone):
             if isinstance(m, ConvParam):
                 nn.init.kaiming_normal_(m.weight)
 
+    def layer_forward(self, layer, buf, table, cin, norm, train):
+        """One _DenseLayer (OriginDenseNet.py:19-36) on the block buffer: reads channels [0, cin) of ``buf``, writes its
+        ``growth`` new channels at [cin, cin+growth) in place (the reference's torch.cat, :36) and merges their batch
+        statistics into ``table`` (the shared [1][2][Ctot] sum / sum-of-squares rows every later norm1 reads)."""
+        dev = buf.t.device
+        N, h, w = buf.N, buf.H, buf.W
+        w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
+        xin = buf.window(0, cin)
+        st1 = norm(table, buf.npix, layer.norm1, cin)
+        t1 = ops.new_act(N, h, w, cin, dev)
+        ops.bn_apply(xin, st1, t1, relu=True)
+        t2 = ops.new_act(N, h, w, w1.Opad, dev)
+        if not train and self.fused_eval:
+            # eval(): norm2 + ReLU ride in the 1x1 convolution's epilogue (norm1 acts on the concat input
+            # and stays a separate pass)
+            y1 = st2 = None
+            ops.conv_fwd_bn_act(t1, w1, t2, ops.bn_eval_state(layer.norm2), relu=True)
+        else:
+            y1 = ops.new_act(N, h, w, w1.Opad, dev)
+            st2 = norm(ops.conv_fwd(t1, w1, y1, train), y1.npix, layer.norm2)
+            ops.bn_apply(y1, st2, t2, relu=True)
+        stats = ops.conv_fwd(t2, w2, buf.window(cin, self.growth), train)
+        if train:
+            ops.stats_merge(stats, table[0], cin)
+        return (layer, cin, st1, t1, y1, st2, t2)
+
+    def transition_forward(self, tr, buf, table, norm):
+        """_Transition (OriginDenseNet.py:47-54) up to the 1x1 convolution; the caller pools ``yc`` into the next block."""
+        dev = buf.t.device
+        cin = buf.C
+        wc = self.cw(tr.conv)
+        st = norm(table, buf.npix, tr.norm, cin)
+        t = ops.new_act(buf.N, buf.H, buf.W, cin, dev)
+        ops.bn_apply(buf, st, t, relu=True)
+        yc = ops.new_act(buf.N, buf.H, buf.W, wc.Opad, dev)
+        ops.conv_fwd(t, wc, yc, False)
+        return ("trans", tr, buf, st, t, yc)
+
+    def layer_backward(self, lrec, buf, G, grads, side):
+        """Backward of one _DenseLayer: ``G`` holds the gradient of the block buffer; the layer's own slice is complete
+        (every later layer has added to it), its input gradient is accumulated into G[..., :cin]."""
+        (layer, cin, st1, t1, y1, st2, t2) = lrec
+        dev = G.t.device
+        N = G.N
+        w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
+        dy2 = G.window(cin, self.growth)
+        mk = side.mark()
+        dt2 = ops.new_act(N, t2.H, t2.W, t2.C, dev)
+        ops.conv_dgrad(dy2, w2, dt2)
+        grads[layer.conv2.weight] = ops.conv_wgrad(t2, dy2, w2, side, after=mk)
+        dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
+        grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward(dt2, y1, st2, layer.norm2, dy1, 2)
+        mk = side.mark()
+        dt1 = ops.new_act(N, t1.H, t1.W, cin, dev)
+        ops.conv_dgrad(dy1, w1, dt1)
+        grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1, side, after=mk)
+        grads[layer.norm1.weight], grads[layer.norm1.bias] = ops.bn_backward(
+            dt1, buf.window(0, cin), st1, layer.norm1, G.window(0, cin), 2, accumulate=True)
+        self._emit(grads, list(layer.parameters()))
+
+    def transition_backward(self, trec, g_first, grads, side):
+        """Backward of one _Transition: ``g_first`` is the gradient of the pooled tensor; returns the gradient of the
+        preceding block buffer."""
+        _, tr, buf, st, t, yc = trec
+        dev = g_first.t.device
+        N = buf.N
+        wc = self.cw(tr.conv)
+        dyc = ops.new_act(N, yc.H, yc.W, yc.C, dev)
+        ops.avgpool_bwd(g_first, dyc)
+        mk = side.mark()
+        dt = ops.new_act(N, t.H, t.W, t.C, dev)
+        ops.conv_dgrad(dyc, wc, dt)
+        grads[tr.conv.weight] = ops.conv_wgrad(t, dyc, wc, side, after=mk)
+        G = ops.new_act(N, buf.H, buf.W, buf.C, dev)
+        grads[tr.norm.weight], grads[tr.norm.bias] = ops.bn_backward(dt, buf, st, tr.norm, G, 2)
+        self._emit(grads, list(tr.parameters()))
+        return G
+
     # ------------------------------------------------------------------ forward executor
     def _run_forward(self, images, train, save):
         dev = images.device
@@ -120,38 +198,15 @@ class DenseNet(HipBackbone):
                     ops.stats_merge(ops.bn_stats(first), table[0], 0)
                 lrecs = []
                 for li, layer in enumerate(getattr(F, name).layers()):
-                    cin = nf + li * self.growth
-                    w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
-                    xin = buf.window(0, cin)
-                    st1 = norm(table, buf.npix, layer.norm1, cin)
-                    t1 = ops.new_act(N, h, w, cin, dev)
-                    ops.bn_apply(xin, st1, t1, relu=True)
-                    t2 = ops.new_act(N, h, w, w1.Opad, dev)
-                    if not train and self.fused_eval:
-                        # eval(): norm2 + ReLU ride in the 1x1 convolution's epilogue (norm1 acts on the concat input
-                        # and stays a separate pass)
-                        y1 = st2 = None
-                        ops.conv_fwd_bn_act(t1, w1, t2, ops.bn_eval_state(layer.norm2), relu=True)
-                    else:
-                        y1 = ops.new_act(N, h, w, w1.Opad, dev)
-                        st2 = norm(ops.conv_fwd(t1, w1, y1, train), y1.npix, layer.norm2)
-                        ops.bn_apply(y1, st2, t2, relu=True)
-                    stats = ops.conv_fwd(t2, w2, buf.window(cin, self.growth), train)
-                    if train:
-                        ops.stats_merge(stats, table[0], cin)
+                    lrec = self.layer_forward(layer, buf, table, nf + li * self.growth, norm, train)
                     if save:
-                        lrecs.append((layer, cin, st1, t1, y1, st2, t2))
+                        lrecs.append(lrec)
                 rec["stages"].append(("block", buf, lrecs, nf))
             else:
                 _, name, cin = item
-                tr = getattr(F, name)
-                wc = self.cw(tr.conv)
-                st = norm(table, buf.npix, tr.norm, cin)
-                t = ops.new_act(N, h, w, cin, dev)
-                ops.bn_apply(buf, st, t, relu=True)
-                yc = ops.new_act(N, h, w, cin // 2, dev)
-                ops.conv_fwd(t, wc, yc, False)
-                rec["stages"].append(("trans", tr, buf, st, t, yc))
+                trec = self.transition_forward(getattr(F, name), buf, table, norm)
+                yc = trec[5]
+                rec["stages"].append(trec)
                 pending_pool = ("avg", yc)
                 h, w = h // 2, w // 2
 
@@ -193,35 +248,11 @@ class DenseNet(HipBackbone):
         for stage in reversed(rec["stages"]):
             if stage[0] == "block":
                 _, buf, lrecs, nf = stage
-                for (layer, cin, st1, t1, y1, st2, t2) in reversed(lrecs):
-                    w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
-                    dy2 = G.window(cin, self.growth)          # the slice is complete: every later layer has added to it
-                    mk = side.mark()
-                    dt2 = ops.new_act(N, t2.H, t2.W, t2.C, dev)
-                    ops.conv_dgrad(dy2, w2, dt2)
-                    grads[layer.conv2.weight] = ops.conv_wgrad(t2, dy2, w2, side, after=mk)
-                    dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
-                    grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward(dt2, y1, st2, layer.norm2, dy1, 2)
-                    mk = side.mark()
-                    dt1 = ops.new_act(N, t1.H, t1.W, cin, dev)
-                    ops.conv_dgrad(dy1, w1, dt1)
-                    grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1, side, after=mk)
-                    grads[layer.norm1.weight], grads[layer.norm1.bias] = ops.bn_backward(
-                        dt1, buf.window(0, cin), st1, layer.norm1, G.window(0, cin), 2, accumulate=True)
-                    self._emit(grads, list(layer.parameters()))
+                for lrec in reversed(lrecs):
+                    self.layer_backward(lrec, buf, G, grads, side)
                 g_first = G.window(0, nf)                     # gradient w.r.t. the pooled tensor that opened the block
             else:
-                _, tr, buf, st, t, yc = stage
-                wc = self.cw(tr.conv)
-                dyc = ops.new_act(N, yc.H, yc.W, yc.C, dev)
-                ops.avgpool_bwd(g_first, dyc)
-                mk = side.mark()
-                dt = ops.new_act(N, t.H, t.W, t.C, dev)
-                ops.conv_dgrad(dyc, wc, dt)
-                grads[tr.conv.weight] = ops.conv_wgrad(t, dyc, wc, side, after=mk)
-                G = ops.new_act(N, buf.H, buf.W, buf.C, dev)
-                grads[tr.norm.weight], grads[tr.norm.bias] = ops.bn_backward(dt, buf, st, tr.norm, G, 2)
-                self._emit(grads, list(tr.parameters()))
+                G = self.transition_backward(stage, g_first, grads, side)
 
         xp, y0, s0, z0, H, W, pidx = rec["stem"]
         w0 = self.cw(F.conv0, stem=True)

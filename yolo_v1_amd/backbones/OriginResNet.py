@@ -110,6 +110,36 @@ class ResNet(HipBackbone):
         ops.conv_fwd(x, wh, yh, False)
         return ops.head_fwd(yh, ops.bn_eval_state(self.bn_end), self.out_channels)
 
+    def block_forward(self, blk, x, x8, norm, conv, q8, save):
+        """One Bottleneck (OriginResNet.py:87-107).  ``norm(stats, count, bn)`` -> BNState, ``conv(x, x8, ConvParam, y)``
+        -> statistic partials, ``q8(act)`` -> e4m3 twin or None.  Returns (out, out8, record for block_backward)."""
+        dev = x.t.device
+        N = x.N
+        planes, cout = blk.conv1.out_channels, blk.conv3.out_channels
+        y1 = ops.new_act(N, x.H, x.W, planes, dev)
+        s1 = norm(conv(x, x8, blk.conv1, y1), y1.npix, blk.bn1)
+        z1 = ops.new_act(N, x.H, x.W, planes, dev)
+        z1_8 = q8(z1)
+        ops.bn_apply(y1, s1, z1, relu=True, z8=z1_8)
+        h2, w2_ = ops.conv_out_hw(x.H, x.W, 3, blk.stride, 1)
+        y2 = ops.new_act(N, h2, w2_, planes, dev)
+        s2 = norm(conv(z1, z1_8, blk.conv2, y2), y2.npix, blk.bn2)
+        z2 = ops.new_act(N, h2, w2_, planes, dev)
+        z2_8 = q8(z2)
+        ops.bn_apply(y2, s2, z2, relu=True, z8=z2_8)
+        y3 = ops.new_act(N, h2, w2_, cout, dev)
+        s3 = norm(conv(z2, z2_8, blk.conv3, y3), y3.npix, blk.bn3)
+        out = ops.new_act(N, h2, w2_, cout, dev)
+        out8 = q8(out)
+        yd = sd = None
+        if blk.downsample is not None:
+            yd = ops.new_act(N, h2, w2_, cout, dev)
+            sd = norm(conv(x, x8, blk.downsample[0], yd), yd.npix, blk.downsample[1])
+            omask = ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd, want_mask=save, z8=out8)
+        else:
+            omask = ops.bn_apply(y3, s3, out, relu=True, residual=x, want_mask=save, z8=out8)
+        return out, out8, (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask)
+
     def _run_forward(self, images, train, save):
         dev = images.device
         N, _, H, W = images.shape
@@ -153,32 +183,9 @@ class ResNet(HipBackbone):
         rec["stem"] = (xp, y0, s0, None, H, W, pidx)
 
         for blk in self._blocks():
-            planes = blk.conv1.out_channels
-            y1 = ops.new_act(N, x.H, x.W, planes, dev)
-            s1 = norm(conv(x, x8, blk.conv1, y1), y1.npix, blk.bn1)
-            z1 = ops.new_act(N, x.H, x.W, planes, dev)
-            z1_8 = q8(z1)
-            ops.bn_apply(y1, s1, z1, relu=True, z8=z1_8)
-            h2, w2_ = ops.conv_out_hw(x.H, x.W, 3, blk.stride, 1)
-            y2 = ops.new_act(N, h2, w2_, planes, dev)
-            s2 = norm(conv(z1, z1_8, blk.conv2, y2), y2.npix, blk.bn2)
-            z2 = ops.new_act(N, h2, w2_, planes, dev)
-            z2_8 = q8(z2)
-            ops.bn_apply(y2, s2, z2, relu=True, z8=z2_8)
-            y3 = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
-            s3 = norm(conv(z2, z2_8, blk.conv3, y3), y3.npix, blk.bn3)
-            out = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
-            out8 = q8(out)
-            yd = sd = None
-            if blk.downsample is not None:
-                yd = ops.new_act(N, h2, w2_, planes * EXPANSION, dev)
-                sd = norm(conv(x, x8, blk.downsample[0], yd), yd.npix, blk.downsample[1])
-                omask = ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd, want_mask=save, z8=out8)
-            else:
-                omask = ops.bn_apply(y3, s3, out, relu=True, residual=x, want_mask=save, z8=out8)
+            x, x8, brec = self.block_forward(blk, x, x8, norm, conv, q8, save)
             if save:
-                rec["blocks"].append((blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask))
-            x, x8 = out, out8
+                rec["blocks"].append(brec)
 
         # head: 1x1 conv -> bn_end -> sigmoid, already NHWC                      (:186-189)
         wh = self.cw(self.layer6)
@@ -189,6 +196,51 @@ class ResNet(HipBackbone):
         if train:
             self._bump_counters(bns)
         return pred, (rec if save else None)
+
+    def block_backward(self, brec, g, grads, side):
+        """Backward of one Bottleneck: ``g`` is the gradient of the block output; fills ``grads`` and returns the gradient of
+        the block input."""
+        (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask) = brec
+        dev = g.t.device
+        N = x.N
+        w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
+        g_in = ops.new_act(N, x.H, x.W, x.C, dev)
+        dy3 = ops.new_act(N, y3.H, y3.W, y3.C, dev)
+        if yd is not None:
+            wd = self.cw(blk.downsample[0])
+            bnd = blk.downsample[1]
+            grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
+            dyd = ops.new_act(N, yd.H, yd.W, yd.C, dev)
+            grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
+            grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side)
+        else:
+            # identity shortcut: its contribution to g_in (g where the block output was positive) is added in
+            # the epilogue of conv1's dgrad below
+            grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
+        # the data gradient (critical path) is enqueued BEFORE the weight gradient that reads the same dy: launched
+        # the other way round, the side stream's wgrad workgroups fill the CUs first and the dgrad waits behind
+        # them (50 us per layer in the trace); this way the wgrad runs beside the bandwidth-bound BN kernels
+        mk = side.mark()
+        dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
+        ops.conv_dgrad(dy3, w3, dz2)
+        grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side, after=mk)
+        dy2 = ops.new_act(N, y2.H, y2.W, y2.C, dev)
+        grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
+        mk = side.mark()
+        dz1 = ops.new_act(N, z1.H, z1.W, z1.C, dev)
+        ops.conv_dgrad(dy2, w2, dz1)
+        grads[blk.conv2.weight] = ops.conv_wgrad(z1, dy2, w2, side, after=mk)
+        dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
+        grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
+        mk = side.mark()
+        if yd is not None:
+            ops.conv_dgrad(dy1, w1, g_in, accumulate=False)
+            ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate
+        else:
+            ops.conv_dgrad_add_masked(dy1, w1, g_in, g, omask)
+        grads[blk.conv1.weight] = ops.conv_wgrad(x, dy1, w1, side, after=mk)
+        self._emit(grads, list(blk.parameters()))
+        return g_in
 
     # ------------------------------------------------------------------ backward executor
     def _run_backward(self, rec, gpred):
@@ -209,46 +261,9 @@ class ResNet(HipBackbone):
         ops.conv_dgrad(dyh, wh, g)
         self._emit(grads, [self.bn_end.weight, self.bn_end.bias, self.layer6.weight])
 
-        for (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask) in reversed(rec["blocks"]):
-            w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
-            g_in = ops.new_act(N, x.H, x.W, x.C, dev)
-            dy3 = ops.new_act(N, y3.H, y3.W, y3.C, dev)
-            if yd is not None:
-                wd = self.cw(blk.downsample[0])
-                bnd = blk.downsample[1]
-                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
-                dyd = ops.new_act(N, yd.H, yd.W, yd.C, dev)
-                grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
-                grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side)
-            else:
-                # identity shortcut: its contribution to g_in (g where the block output was positive) is added in
-                # the epilogue of conv1's dgrad below
-                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
-            # the data gradient (critical path) is enqueued BEFORE the weight gradient that reads the same dy: launched
-            # the other way round, the side stream's wgrad workgroups fill the CUs first and the dgrad waits behind
-            # them (50 us per layer in the trace); this way the wgrad runs beside the bandwidth-bound BN kernels
-            mk = side.mark()
-            dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
-            ops.conv_dgrad(dy3, w3, dz2)
-            grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side, after=mk)
-            dy2 = ops.new_act(N, y2.H, y2.W, y2.C, dev)
-            grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
-            mk = side.mark()
-            dz1 = ops.new_act(N, z1.H, z1.W, z1.C, dev)
-            ops.conv_dgrad(dy2, w2, dz1)
-            grads[blk.conv2.weight] = ops.conv_wgrad(z1, dy2, w2, side, after=mk)
-            dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
-            grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
-            mk = side.mark()
-            if yd is not None:
-                ops.conv_dgrad(dy1, w1, g_in, accumulate=False)
-                ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate
-            else:
-                ops.conv_dgrad_add_masked(dy1, w1, g_in, g, omask)
-            grads[blk.conv1.weight] = ops.conv_wgrad(x, dy1, w1, side, after=mk)
-            self._emit(grads, list(blk.parameters()))
-            g = g_in
-            if self._phase_boundary is not None and blk is boundary_blk:
+        for brec in reversed(rec["blocks"]):
+            g = self.block_backward(brec, g, grads, side)
+            if self._phase_boundary is not None and brec[0] is boundary_blk:
                 side.join()
                 self._phase_boundary(grads)
 

@@ -93,7 +93,12 @@ class GraphedStep:
     (DenseNet-121: 38 MB of gradients) use one graph and one collective.
     """
 
-    def __init__(self, net, loss_layer, optimizer, images, target, grad_sync=None, warmup=3, two_phase=None):
+    def __init__(self, net, loss_layer, optimizer, images, target, grad_sync=None, warmup=3, two_phase=None,
+                 preserve_state=False):
+        """``preserve_state``: the eager warm-up steps that precede the capture (lazy initialisation, allocator warm-up)
+        are real training steps; with this flag the parameters, BatchNorm buffers and momentum buffers are put back
+        afterwards, so the first replay IS iteration 1 of the run (``train.main``); bench.py counts them as warm-up."""
+        from . import ops
         from .optim import FusedSGD
         if not isinstance(optimizer, FusedSGD):
             raise TypeError("GraphedStep needs yolo_v1_amd.optim.FusedSGD (device-side learning rate)")
@@ -108,6 +113,7 @@ class GraphedStep:
             net.set_grad_ready_hook(None)          # buckets are issued between / after the replays, not from inside a capture
         self.steps_done = 0
         self.phase1 = None                          # [(param, grad)] finished at the phase boundary
+        snap = [(t, t.detach().clone()) for t in net.state_dict().values()] if preserve_state else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up on a side stream: lazy inits, allocator, hipFuncSetAttribute
@@ -115,6 +121,17 @@ class GraphedStep:
                 self._body(eager=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if snap is not None:
+            with torch.no_grad():
+                for t, c in snap:
+                    t.copy_(c)
+                for p in net.parameters():
+                    st = optimizer.state.get(p)
+                    if st and 'momentum_buffer' in st:
+                        st['momentum_buffer'].zero_()      # zeros == "no buffer yet": buf = momentum*0 + g on the first step
+            ops.bump_weight_epoch()
+            self.steps_done = 0
+            torch.cuda.synchronize()
         if self.in_graph_step:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
@@ -186,24 +203,52 @@ class GraphedStep:
         self.sync.reduce_all([(p, p.grad) for p in self.net.parameters() if p.grad is not None and id(p) not in done])
         self.opt.step()
 
-    def __call__(self, lr):
+    def _dp_sequence(self, replay1, replay2):
+        """The multi-rank step around the two replays: phase 1 -> asynchronous all-reduce of the gradients finished at
+        the phase boundary (RCCL's stream, beside the second replay) -> phase 2 -> one more collective for the rest ->
+        optimizer.  Kept apart from the graph objects so the CPU gloo test drives this exact sequence."""
         from . import ops
-        self.opt.set_lr(lr)
-        self.graph.replay()
-        if self.in_graph_step:
-            ops.bump_weight_epoch()
-            return self.loss
+        replay1()
         early = None
         if self.two_phase:
             early = self.phase1
-            self.sync.start(early)                 # asynchronous: RCCL's stream, beside the second graph
-            self.graph2.replay()
+            self.sync.start(early)
+            replay2()
         ops.bump_weight_epoch()
         self._reduce_and_step(early)
+
+    def __call__(self, lr):
+        from . import ops
+        self.opt.set_lr(lr)
+        if self.in_graph_step:
+            self.graph.replay()
+            ops.bump_weight_epoch()
+            return self.loss
+        self._dp_sequence(self.graph.replay, self.graph2.replay if self.two_phase else None)
         return self.loss
 
 
-def main(argv=None):
+def sync_replicas(net):
+    """Makes every rank's replica identical to rank 0's before the first step: broadcasts every state_dict tensor
+    (parameters AND BatchNorm buffers).  The reference has a single replica (nn.DataParallel(device_ids=[0]),
+    train.py:34,:80); here each process builds its own, and gradient averaging only keeps replicas equal if they start
+    equal.  c10d writes the tensors in place without bumping torch's version counter, so the bf16 weight shadows are
+    told explicitly."""
+    import torch.distributed as dist
+    from . import ops
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in net.state_dict().values():
+            dist.broadcast(t, 0)
+    ops.bump_weight_epoch()
+
+
+def main(argv=None, return_losses=False):
+    """The epoch loop of train.py:144-209.  Default path = the one bench.py measures: fused HIP SGD, the whole step
+    replayed from hipGraphs (``GraphedStep``), static input buffers filled by the device prefetcher, the loss read back
+    only when the log line needs it (every 5th iteration, train.py:175-177) -- ``average_loss`` is accumulated on the
+    device (and the loss layer's four per-iteration component log lines, v1Loss.py:107-116, which need a host sync each,
+    are off).  ``--eager`` launches kernel by kernel (same kernels, same results bit for bit, the component log lines on);
+    ``--torch-sgd`` additionally swaps the fused optimizer for torch.optim.SGD (train.py:84)."""
     ap = argparse.ArgumentParser(description="YOLO-v1 training on MI355X (reference train.py surface)")
     ap.add_argument("--backbone", default=DEFAULTS["backbone"], choices=["densenet", "resnet"])
     ap.add_argument("--S", type=int, default=DEFAULTS["S"])
@@ -211,6 +256,10 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=DEFAULTS["num_epochs"])
     ap.add_argument("--iters-per-epoch", type=int, default=20, help="synthetic data: iterations per epoch")
     ap.add_argument("--save-dir", default=None)
+    ap.add_argument("--seed", type=int, default=0, help="weight-init seed (every rank ends up with rank 0's weights)")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--torch-sgd", action="store_true", help="torch.optim.SGD (train.py:84) instead of the fused HIP SGD; "
+                                                             "implies --eager")
     ap.add_argument("--pretrained", default=None, help="ImageNet state_dict file (torchvision keys) for the by-name "
                                                        "initialisation of train.py:59-78; no network access here")
     ap.add_argument("--resume", default=None, help="checkpoint written by this script or by the reference")
@@ -220,8 +269,16 @@ def main(argv=None):
     ap.add_argument("--loader", action="store_true",
                     help="feed every step from a DataLoader (synthetic yoloDataset, 4 workers as train.py:119) through "
                          "the device prefetcher + device target encoder instead of one resident batch")
+    ap.add_argument("--val-list", default=None, help="validation image list (train.py:114-131): per-epoch little-mAP, full "
+                                                    "mAP above --full-map-thresh, <name>_best.pth on improvement")
+    ap.add_argument("--val-synthetic", type=int, default=0, help="validate on this many synthetic samples instead (plumbing)")
+    ap.add_argument("--little-val-num", type=int, default=750)                                   # train.py:129
+    ap.add_argument("--full-map-thresh", type=float, default=0.585)                              # train.py:141 (HEAD side)
+    ap.add_argument("--workers", type=int, default=4)                                            # train.py:119
     args = ap.parse_args(argv)
+    from . import checkpoint
     from . import distributed as ydist
+    from . import ops
     from .utils.YOLODataLoader import synthetic_batch
     from .utils.utils import create_logger
     rank, world, device = ydist.init_from_env()
@@ -229,58 +286,121 @@ def main(argv=None):
     opt_name = 'sgd'
     base = args.save_dir or '%s_%s_cellSize%d/' % (args.backbone, opt_name, args.S)              # train.py:91
     logger = create_logger(base, 'train') if rank == 0 else None
+    torch.manual_seed(args.seed)
+    fast = not (args.eager or args.torch_sgd)
     net, loss_layer, opt = build(args.backbone, args.S, DEFAULTS["B"], DEFAULTS["clsN"], bs, device, logger=logger,
-                                 quiet=rank != 0)
+                                 quiet=(rank != 0 or fast), fused_optimizer=not args.torch_sgd)
     if args.fp8_forward:
         net.fp8_forward = True
-    if args.pretrained or args.resume:
-        from . import checkpoint
-        if args.pretrained:
-            taken = checkpoint.init_from_pretrained(net, torch.load(args.pretrained, map_location='cpu', weights_only=True))
-            if logger:
-                logger.info('initialised %d tensors by name from %s' % (len(taken), args.pretrained))
-        if args.resume:
-            checkpoint.load(net, args.resume, device)
+    if args.pretrained:
+        taken = checkpoint.init_from_pretrained(net, torch.load(args.pretrained, map_location='cpu', weights_only=True))
+        if logger:
+            logger.info('initialised %d tensors by name from %s' % (len(taken), args.pretrained))
+    if args.resume:
+        checkpoint.load(net, args.resume, device)
+    sync_replicas(net)                               # after init / --pretrained / --resume, before the first forward
     sync = ydist.GradSync(net) if world > 1 else None
+
+    # ---- data: one resident synthetic batch, or a DataLoader behind the device prefetcher (sharded over the ranks)
     images, target = synthetic_batch(bs, args.S, seed=1234 + rank, device=device)
-    feed = None
+    feed = sampler = None
     if args.loader or args.list_file:
         from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
         from .utils.YOLODataLoader import DevicePrefetcher, collate_raw, yoloDataset
-        ds = yoloDataset(args.list_file, S=args.S, B=DEFAULTS["B"], C=DEFAULTS["clsN"], raw_targets=True, seed=1234 + rank,
-                         length=bs * args.iters_per_epoch)
-        if args.list_file:
-            args.iters_per_epoch = max(1, len(ds) // bs)
-        feed = DevicePrefetcher(DataLoader(ds, batch_size=bs, shuffle=True, num_workers=4, collate_fn=collate_raw,
-                                           drop_last=True), device, args.S, DEFAULTS["B"], DEFAULTS["clsN"])
+        ds = yoloDataset(args.list_file, S=args.S, B=DEFAULTS["B"], C=DEFAULTS["clsN"], raw_targets=True, seed=1234,
+                         length=bs * args.iters_per_epoch * world)
+        if world > 1:        # every rank walks its own 1/world of each epoch's permutation (the reference: one process)
+            sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=args.seed, drop_last=True)
+        loader = DataLoader(ds, batch_size=bs, shuffle=(sampler is None), sampler=sampler, num_workers=args.workers,
+                            collate_fn=collate_raw, drop_last=True)
+        args.iters_per_epoch = max(1, len(loader))
+        feed = DevicePrefetcher(loader, device, args.S, DEFAULTS["B"], DEFAULTS["clsN"],
+                                out_images=images if fast else None, out_target=target if fast else None)
+
+    # ---- validation set (train.py:114-131)
+    val_ds = gt_little = gt_full = None
+    if args.val_list or args.val_synthetic:
+        from .utils.utils import prep_test_data
+        from .utils.YOLODataLoader import yoloDataset
+        if args.val_list:
+            val_ds = yoloDataset(args.val_list, train=False, with_file_path=True, S=args.S)
+            gt_full = prep_test_data(args.val_list, little_test=None)
+            gt_little = prep_test_data(args.val_list, little_test=args.little_val_num)
+        else:
+            val_ds = yoloDataset(None, train=False, with_file_path=True, S=args.S, length=args.val_synthetic, seed=4321)
+            gt_full = val_ds.synthetic_ground_truth()
+            gt_little = val_ds.synthetic_ground_truth(min(args.little_val_num, args.val_synthetic))
+
+    graphed = None
+    if fast:
+        for g in opt.param_groups:
+            g['lr'] = 0.0                                          # capture warm-up steps must not move the weights
+        graphed = GraphedStep(net, loss_layer, opt, images, target, sync, warmup=2, preserve_state=True)
+    total_dev = torch.zeros((), dtype=torch.float32, device=device)
+    history = torch.zeros(max(1, args.epochs * args.iters_per_epoch), dtype=torch.float32, device=device) if return_losses else None
     lr, it = DEFAULTS["learning_rate"], 0
+    best_mAP, last_little_mAP = 0.0, 0.0
     for epoch in range(args.epochs):
+        net.train()
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         if logger:
             logger.info('\n\nStarting epoch %d / %d' % (epoch + 1, args.epochs))
             logger.info('Learning Rate for this epoch: {}'.format(opt.param_groups[0]['lr']))
-        total_loss, t_epoch = 0., time.perf_counter()
+        t_epoch = time.perf_counter()
+        total_dev.zero_()
         batches = iter(feed) if feed is not None else None
         for i in range(args.iters_per_epoch):
             t0 = time.perf_counter()
             if batches is not None:
-                images, target = next(batches)
+                images, target = next(batches)          # fast path: the prefetcher wrote the graph's static buffers
             it += 1
             lr = learning_rate_policy(it, epoch, lr, DEFAULTS["lr_adjust_map"])
-            loss = train_step(net, loss_layer, opt, images, target, lr, sync)
-            total_loss += loss.item()                                                            # train.py:168
-            dt = time.perf_counter() - t0
+            if graphed is not None:
+                loss = graphed(lr)
+            else:
+                loss = train_step(net, loss_layer, opt, images, target, lr, sync)
+            total_dev += loss.detach()                                                           # train.py:168, no host sync
+            if history is not None:
+                history[it - 1].copy_(loss.detach())
             if (i + 1) % 5 == 0 and logger:
+                now, tot = float(loss.item()), float(total_dev.item())     # the only host syncs of the loop
+                dt = time.perf_counter() - t0
                 logger.info('Epoch [%d/%d], Iter [%d/%d] expect end in %.2f min. Loss: %.4f, average_loss: %.4f, '
                             'now learning rate: %f' % (epoch + 1, args.epochs, i + 1, args.iters_per_epoch,
-                                                       dt * (args.iters_per_epoch - i + 1) // 60, loss.item(),
-                                                       total_loss / (i + 1), lr))               # train.py:177
+                                                       dt * (args.iters_per_epoch - i + 1) // 60, now,
+                                                       tot / (i + 1), lr))                       # train.py:177
+        torch.cuda.synchronize(device) if torch.cuda.is_available() else None
+        ep_s = time.perf_counter() - t_epoch
         if logger:
-            logger.info('Epoch {} / {} finished, cost time {:.2f} min.'.format(epoch, args.epochs,
-                                                                              (time.perf_counter() - t_epoch) / 60))
+            logger.info('Epoch {} / {} finished, cost time {:.2f} min. expect {} min finish train.'.format(
+                epoch, args.epochs, ep_s / 60, (ep_s / 60) * (args.epochs - epoch + 1)))
+            logger.info('train throughput: %.1f img/s on this rank (%d iterations of batch %d)' % (
+                args.iters_per_epoch * bs / ep_s, args.iters_per_epoch, bs))
+        # ---- validation + checkpoints (train.py:187-209), rank 0 (DataParallel's single replica)
         if rank == 0:
             os.makedirs(base, exist_ok=True)
-            from . import checkpoint                                       # nn.DataParallel key prefix (train.py:80,:209)
-            checkpoint.save(net, '%s/%s_%s_S%d_yolo.pth' % (base, args.backbone, opt_name, args.S))
+            if val_ds is not None:
+                from copy import deepcopy
+                from .utils.utils import run_test_mAP
+                net.eval()
+                test_mAP = 0.0
+                data_len = int(len(val_ds) / bs)
+                little = min(args.little_val_num, len(val_ds))
+                now_little_mAP = run_test_mAP(net, deepcopy(gt_little), val_ds, data_len, S=args.S, device=device,
+                                              logger=logger, little_test=little)
+                if now_little_mAP > last_little_mAP and now_little_mAP > args.full_map_thresh:
+                    test_mAP = run_test_mAP(net, deepcopy(gt_full), val_ds, data_len, S=args.S, device=device, logger=logger)
+                last_little_mAP = now_little_mAP
+                if test_mAP > best_mAP:
+                    best_mAP = test_mAP
+                    logger.info('get best test mAP %.5f' % best_mAP)
+                    checkpoint.save(net, '%s/%s_%s_S%d_best.pth' % (base, args.backbone, opt_name, args.S))
+                net.train()
+            checkpoint.save(net, '%s/%s_%s_S%d_yolo.pth' % (base, args.backbone, opt_name, args.S))   # train.py:209
+    if return_losses:
+        return history.cpu().tolist()[:it]
 
 
 if __name__ == "__main__":
