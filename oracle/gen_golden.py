@@ -335,6 +335,11 @@ def gen_blocks(rr, rdn):
     run("bneck_plain", rr.Bottleneck(64, 16), torch.randn(2, 64, 6, 6))
     run("dense_layer", rdn._DenseLayer(64, 32, 4, 0), torch.randn(2, 64, 8, 8))
     run("transition", rdn._Transition(64, 32), torch.randn(2, 64, 8, 8))
+    # round 2: the same stride-2 projection block on a 16x16 input (its BatchNorms after the stride then see 128 samples
+    # per channel instead of 32: gate flips of the bf16 path no longer dominate its gradients) and an identity block at
+    # widths the HIP kernels take without zero-padding
+    run("bneck_s2_ds_16", rr.Bottleneck(64, 32, 2, ds(64, 128, 2)), torch.randn(2, 64, 16, 16))
+    run("bneck_plain_32", rr.Bottleneck(128, 32), torch.randn(2, 128, 12, 12))
     np.savez_compressed(os.path.join(OUT, "block_cases.npz"), **out)
     print("block fixtures:", len(out), "arrays")
 

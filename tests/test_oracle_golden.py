@@ -119,6 +119,8 @@ def _block(name):
     ("bneck_s1_ds", lambda x, P: ob.bottleneck(x, P, "", 1)),
     ("bneck_s2_ds", lambda x, P: ob.bottleneck(x, P, "", 2)),
     ("bneck_plain", lambda x, P: ob.bottleneck(x, P, "", 1)),
+    ("bneck_s2_ds_16", lambda x, P: ob.bottleneck(x, P, "", 2)),
+    ("bneck_plain_32", lambda x, P: ob.bottleneck(x, P, "", 1)),
     ("dense_layer", lambda x, P: ob.dense_layer(x, P, "")),
     ("transition", lambda x, P: ob.transition(x, P, "")),
 ])

@@ -66,6 +66,7 @@ struct ConvArgs {
   int ldres = 0, erelu = 0;
   int M;
   int MT, NT;
+  int slots = 0;       // k_conv_ps: workgroups per column tile; workgroup (slot, nt) walks the pixel tiles slot, slot+slots, ...
   int dbg = 0;         // tuning only: bit0 skip the in-loop global loads / LDS stores, bit1 skip the MFMA block
 };
 
@@ -590,6 +591,466 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) 
   conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
 }
 
+// ---- persistent form of k_conv_dma ---------------------------------------------------------------------------
+// Same tiles, ring, swizzle and MFMA loop, but a workgroup owns ONE column tile (nt) and walks the pixel tiles
+// slot, slot + slots, slot + 2 slots ... of it:
+//   * the first NST-1 K-steps of the NEXT pixel tile are issued (LDS-DMA) before the epilogue of the current one, so the
+//     global-load latency of a tile is spent under the previous tile's epilogue instead of in front of its first MFMA
+//     (the small-K 1x1 layers are load -> 16 MFMAs -> store: their tile lifetime was latency, not work);
+//   * the epilogue has NO workgroup barrier: each wave packs its own sub-tile through a wave-private staging area --
+//     16 pixel rows at a time, inside the ring stage the prefetch leaves free (stage NST-1) -- and stores full 128-B+
+//     channel runs; waves drift apart across tiles instead of meeting three times per tile;
+//   * BatchNorm statistic partials are accumulated in registers over all the tiles of the workgroup and written ONCE:
+//     `slots` partial rows per launch instead of one per pixel tile (6272 -> 384 rows on the 112x112 maps), which is
+//     what the finalize kernels then read;
+//   * the epilogue's stores stay in flight across the next tile's first K-steps: the counted vmcnt of those steps
+//     includes them (VM operations retire in issue order: the prefetch is OLDER than the stores, so waiting for it
+//     does not wait for them).
+// workgroups of k_conv_ps<...> a CU holds: by LDS (160 KB per CU), at most 3 (2 for the 128x256 tile: 128 accumulator VGPRs)
+template <int BM, int BN, int BK, int NST>
+constexpr int ps_wgs_per_cu() {
+  constexpr int lds = NST * (BM + BN) * BK * 2;
+  constexpr int by_lds = (160 * 1024) / lds;
+  constexpr int cap = BM * BN <= 128 * 128 ? 3 : 2;
+  return by_lds < 1 ? 1 : (by_lds < cap ? by_lds : cap);
+}
+
+// PLAIN: the training launches -- raw bf16 output in pixel order (+ optional statistics), no scale/shift/ReLU, no
+// residual, no accumulate / shortcut-gradient reads.  Its loop contains no ordinary global load, so nothing makes the
+// compiler drain the LDS-DMA queue (hipcc waits vmcnt(0) for any VGPR-destination load while a DMA is in flight) and the
+// prefetch really flies under the epilogue; the generic form is correct with any epilogue but drains there.
+template <int BM, int BN, int BK, int WM, int WN, int NST, bool PLAIN>
+__global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>())) k_conv_ps(ConvArgs a) {
+  constexpr int NTH = WM * WN * 64;
+  constexpr int CPR = BK / 8;
+  constexpr int RPP = NTH / CPR;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tiles must be whole passes");
+  constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP, LPS = A_PASSES + B_PASSES;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int CW = BN / WN;                                  // channels per wave
+  constexpr int CPW = CW / 8;                                  // 16-B chunks per staged row
+  constexpr int SPITCH = (CW / 2 % 32 == 16) ? CW * 2 : CW * 2 + 64;   // bytes; pitch/4 % 32 == 16: conflict-free ds_write_b32
+  constexpr int SROWS = 16;                                    // rows staged at a time (half of a 32x32 block)
+  constexpr int SPASSES = SROWS * CPW / 64;                    // 16-B stores per lane and staged half
+  static_assert(SROWS * CPW % 64 == 0 && WM * WN * SROWS * SPITCH <= STAGE, "staging area must fit the free ring stage");
+  constexpr int ESTORES = TM * 2 * SPASSES;                    // store instructions a wave issues per (full) tile
+  static_assert(2 * LPS + ESTORES < 64 && NST >= 2, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  int nt, slot;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    slot = lin / a.NT;                                         // the column tiles of one pixel tile run side by side on one XCD
+    nt = lin - slot * a.NT;
+  }
+  const int n0 = nt * BN;
+  const int S = a.slots;
+
+  const int cslot = tid % CPR, rrow = tid / CPR;
+  const int lchunk = swz<BK>(rrow, cslot);
+  int pix_base[A_PASSES], ph[A_PASSES], qw[A_PASSES];
+  const bool direct = a.R * a.S == 1 && a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0 && a.log2d == 0 &&
+                      a.P == a.IH && a.Q == a.IW;
+  const int cblocks = a.Cin / BK;
+  const int nk = a.R * a.S * cblocks;
+  const int dmask = (1 << a.log2d) - 1;
+  int woff[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) woff[i] = (n0 + rrow + i * RPP) * a.Kw + lchunk * 8;
+  const int piece_row0 = (wid * 64) / CPR;
+
+  // ---- loader: runs ahead of the MFMA loop, across tile boundaries
+  int ld_mt = slot;                                            // pixel tile the loader is fetching
+  int ld_r = 0, ld_s = 0, ld_cb = 0;
+  const bf16_t* asrc[A_PASSES];
+  int astep[A_PASSES];
+  const bf16_t* wsrc[B_PASSES];
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+#define YV1_SET_TAP_P()                                                                                          \
+  {                                                                                                              \
+    const int wtap_off = ((a.wr0 + ld_r * a.wrs) * a.WS + (a.ws0 + ld_s * a.wss)) * a.Cin;                       \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const int hn = ph[i] + ld_r * a.bh, wn_ = qw[i] + ld_s * a.bw;                                             \
+      const int ih = hn >> a.log2d, iw = wn_ >> a.log2d;                                                         \
+      const bool ok = pix_base[i] >= 0 && ((hn | wn_) & dmask) == 0 && hn >= 0 && wn_ >= 0 && ih < a.IH &&       \
+                      iw < a.IW;                                                                                 \
+      asrc[i] = ok ? a.X + ((size_t)(pix_base[i] + ih * a.IW + iw) * a.ldx + lchunk * 8) : zsrc;                 \
+      astep[i] = ok ? BK : 0;                                                                                    \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) wsrc[i] = a.W + (woff[i] + wtap_off);                   \
+  }
+#define YV1_SET_TILE_P()                                                                                         \
+  {                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      const int m = ld_mt * BM + rrow + i * RPP;                                                                 \
+      if (m < a.M) {                                                                                             \
+        if (direct) {                                                                                            \
+          pix_base[i] = m; ph[i] = 0; qw[i] = 0;                                                                 \
+        } else {                                                                                                 \
+          const int pq = a.P * a.Q;                                                                              \
+          const int n = m / pq, rem = m - n * pq;                                                                \
+          const int p = rem / a.Q, q = rem - p * a.Q;                                                            \
+          pix_base[i] = n * a.IH * a.IW;                                                                         \
+          ph[i] = p * a.ah + a.ch;                                                                               \
+          qw[i] = q * a.aw + a.cw;                                                                               \
+        }                                                                                                        \
+      } else {                                                                                                   \
+        pix_base[i] = -1; ph[i] = 0; qw[i] = 0;                                                                  \
+      }                                                                                                          \
+    }                                                                                                            \
+    ld_r = 0; ld_s = 0; ld_cb = 0;                                                                               \
+    YV1_SET_TAP_P();                                                                                             \
+  }
+#define YV1_ISSUE_P(STG_)                                                                                        \
+  {                                                                                                              \
+    unsigned char* sa_ = smem + (STG_) * STAGE;                                                                  \
+    unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
+      __builtin_amdgcn_global_load_lds((glb_void*)asrc[i], (lds_void*)(sa_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+      asrc[i] += astep[i];                                                                                       \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i) {                                                       \
+      __builtin_amdgcn_global_load_lds((glb_void*)wsrc[i], (lds_void*)(sb_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+      wsrc[i] += BK;                                                                                             \
+    }                                                                                                            \
+    if (++ld_cb == cblocks) {                                                                                    \
+      ld_cb = 0;                                                                                                 \
+      if (++ld_s == a.S) { ld_s = 0; ++ld_r; }                                                                   \
+      if (ld_r == a.R) {                                 /* last K-step of this tile: move on to the next tile */ \
+        ld_mt += S;                                                                                              \
+        if (ld_mt < a.MT) YV1_SET_TILE_P();                                                                      \
+      } else {                                                                                                   \
+        YV1_SET_TAP_P();                                                                                         \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  constexpr int KS = BK / 16;
+  int fa_off[TM][KS], fb_off[TN][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (BM / WM) + i * 32 + l31;
+      fa_off[i][ks] = row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * (BN / WN) + j * 32 + l31;
+      fb_off[j][ks] = A_BYTES + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16;
+    }
+  }
+#define YV1_MFMA_BLOCK_P(BASE_)                                                                                  \
+  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                            \
+    bf16x8 fa[TM], fb[TN];                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>((BASE_) + fa_off[i][ks]); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>((BASE_) + fb_off[j][ks]); \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);                   \
+  }
+
+  // BatchNorm statistics of this workgroup's column tile, summed over all its pixel tiles (lane = channel, see below)
+  float st_s[TN], st_ss[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { st_s[j] = 0.f; st_ss[j] = 0.f; }
+
+  // wave-private staging area inside ring stage NST-1, and this lane's place in the store passes
+  unsigned char* stg = smem + (NST - 1) * STAGE + wid * (SROWS * SPITCH);
+  const bool odd = lane & 1;
+  constexpr int SSTEP = (64 / CPW) * SPITCH;                   // bytes between a lane's rows of consecutive store passes
+  static_assert(3 * SSTEP < 65536, "ds_read offset field");
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const unsigned stg_rd = (unsigned)(unsigned long)(lds_u8*)(stg + (lane / CPW) * SPITCH + (lane % CPW) * 16);   // LDS byte address
+
+  YV1_SET_TILE_P();
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nk) YV1_ISSUE_P(p);
+  int after_epilogue = 0;                                      // 1: ESTORES stores of the previous tile are younger than the prefetch
+
+  for (int mt = slot; mt < a.MT; mt += S) {
+    const int m0 = mt * BM;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int kt = 0;
+    {
+      const int n_main = nk - (NST - 1);
+      for (; kt + NST <= n_main; kt += NST) {
+#pragma unroll
+        for (int c = 0; c < NST; ++c) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads / staging reads complete before the barrier
+          // the first NST-1 steps after an epilogue: its stores are younger than the step waited for, older than the
+          // steps issued since -- leave them in flight
+          if (kt == 0 && c < NST - 1 && after_epilogue) wait_vmcnt<(NST - 2) * LPS + ESTORES>();
+          else wait_vmcnt<(NST - 2) * LPS>();
+          __builtin_amdgcn_s_barrier();
+          YV1_ISSUE_P((c + NST - 1) % NST);
+          YV1_MFMA_BLOCK_P(smem + c * STAGE);
+        }
+      }
+    }
+    int cur = 0, nxt = NST - 1;
+    for (; kt < nk; ++kt) {
+      const int younger = min(nk - 1 - kt, NST - 2);           // K-steps of THIS tile in flight behind step kt
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (after_epilogue && kt < NST - 1) {                    // step kt was prefetched before the epilogue: its stores are younger
+        if (younger >= 2) wait_vmcnt<2 * LPS + ESTORES>();
+        else if (younger == 1) wait_vmcnt<LPS + ESTORES>();
+        else wait_vmcnt<ESTORES>();
+      } else {
+        if (younger >= 2) wait_vmcnt<2 * LPS>();
+        else if (younger == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST - 1 < nk) YV1_ISSUE_P(nxt);
+      YV1_MFMA_BLOCK_P(smem + cur * STAGE);
+      cur = cur + 1 == NST ? 0 : cur + 1;
+      nxt = nxt + 1 == NST ? 0 : nxt + 1;
+    }
+    // every wave has finished reading the ring: the next tile's first K-steps may land in stages 0 .. NST-2 while the
+    // epilogue runs; stage NST-1 is the staging area
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = mt + S < a.MT;
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < NST - 1; ++p)
+        if (p < nk) YV1_ISSUE_P(p);
+    }
+
+    // ---- epilogue, per wave (no workgroup barrier)
+    const bool full = m0 + BM <= a.M;
+    if (a.stats) {
+      // C/D layout of 32x32: col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel); rows past M are zero
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = acc[i][j][e];
+            s += v;
+            ss += v * v;
+          }
+        st_s[j] += s;
+        st_ss[j] += ss;
+      }
+    }
+    const bool affine = !PLAIN && (a.escale != nullptr || a.erelu);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        // accumulators -> bf16 rows in the staging area: lanes swap one value with their neighbour (DPP) so that each owns
+        // a channel pair of one row, rounded by v_cvt_pk_bf16_f32
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = j * 32 + l31;                        // channel inside the wave's CW
+          float al = 1.f, be = 0.f, lo_clamp = -3.0e38f;
+          if constexpr (!PLAIN) {
+            if (a.escale) { al = a.escale[n0 + wn * CW + col]; be = a.eshift[n0 + wn * CW + col]; }
+            if (a.erelu && !a.ERES) lo_clamp = 0.f;
+          }
+#pragma unroll
+          for (int e8 = 0; e8 < 8; e8 += 2) {
+            const int e = hb * 8 + e8;
+            const float mine_lo = affine ? fmaxf(acc[i][j][e] * al + be, lo_clamp) : acc[i][j][e];
+            const float mine_hi = affine ? fmaxf(acc[i][j][e + 1] * al + be, lo_clamp) : acc[i][j][e + 1];
+            const float send = odd ? mine_lo : mine_hi;
+            const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
+            const int lrow = ((e8 + (odd ? 1 : 0)) & 3) + 8 * (e8 >> 2) + 4 * lh;     // row inside the 16-row half
+            const unsigned v = odd ? cvt_pk_bf16(recv, mine_hi) : cvt_pk_bf16(mine_lo, recv);
+            *reinterpret_cast<unsigned*>(stg + lrow * SPITCH + (col & ~1) * 2) = v;
+          }
+        }
+        // full-line stores of the 16 staged rows.  The same wave wrote them and LDS operations of a wave complete in order,
+        // so no barrier; the reads are inline asm because hipcc would put s_waitcnt vmcnt(0) in front of a ds_read it
+        // can see while an LDS-DMA is in flight (it cannot tell the staging area from the ring stages being filled) --
+        // exactly the drain this kernel exists to avoid.  Loads and their wait are one statement (early-clobber outputs).
+        u32x4 sv[SPASSES];
+        if constexpr (SPASSES == 1) {
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(sv[0]) : "v"(stg_rd) : "memory");
+        } else if constexpr (SPASSES == 2) {
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(sv[0]), "=&v"(sv[1]) : "v"(stg_rd), "i"(SSTEP) : "memory");
+        } else {
+          static_assert(SPASSES == 4, "staging passes");
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\t"
+                       "ds_read_b128 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(sv[0]), "=&v"(sv[1]), "=&v"(sv[2]), "=&v"(sv[3])
+                       : "v"(stg_rd), "i"(SSTEP), "i"(2 * SSTEP), "i"(3 * SSTEP) : "memory");
+        }
+#pragma unroll
+        for (int sp = 0; sp < SPASSES; ++sp) {
+          const int idx = lane + sp * 64;
+          const int row = idx / CPW, cc = idx - row * CPW;
+          const int m = m0 + wm * (BM / WM) + i * 32 + hb * 16 + row;
+          const int nch = n0 + wn * CW + cc * 8;
+          uint4 v = make_uint4(sv[sp][0], sv[sp][1], sv[sp][2], sv[sp][3]);
+          if (full || m < a.M) {
+            size_t off;
+            if (PLAIN || a.os == 1) {
+              off = (size_t)m * a.ldy + nch;
+            } else {
+              const int pq = a.P * a.Q;
+              const int n = m / pq, rem = m - n * pq;
+              const int p = rem / a.Q, q = rem - p * a.Q;
+              off = ((size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0) * a.ldy + nch;
+            }
+            if (!PLAIN && a.AS) {
+              const uint4 o = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + nch);
+              const unsigned mb = a.AM[(size_t)m * a.ldam + (nch >> 3)];
+              const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+              const unsigned* po = reinterpret_cast<const unsigned*>(&o);
+              unsigned res[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(pv[k] << 16) + (((mb >> (2 * k)) & 1u) ? __uint_as_float(po[k] << 16) : 0.f);
+                const float hi = __uint_as_float(pv[k] & 0xffff0000u) +
+                                 (((mb >> (2 * k + 1)) & 1u) ? __uint_as_float(po[k] & 0xffff0000u) : 0.f);
+                res[k] = pack_bf16x2(lo, hi);
+              }
+              v = make_uint4(res[0], res[1], res[2], res[3]);
+            }
+            if (!PLAIN && a.ERES) {
+              const uint4 o = *reinterpret_cast<const uint4*>(a.ERES + (size_t)m * a.ldres + nch);
+              const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+              const unsigned* po = reinterpret_cast<const unsigned*>(&o);
+              const float lo_clamp = a.erelu ? 0.f : -3.0e38f;
+              unsigned res[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float lo = fmaxf(__uint_as_float(pv[k] << 16) + __uint_as_float(po[k] << 16), lo_clamp);
+                const float hi = fmaxf(__uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(po[k] & 0xffff0000u), lo_clamp);
+                res[k] = pack_bf16x2(lo, hi);
+              }
+              v = make_uint4(res[0], res[1], res[2], res[3]);
+            }
+            if (!PLAIN && a.accumulate) {
+              const uint4 o = *reinterpret_cast<const uint4*>(a.Y + off);
+              const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+              const unsigned* po = reinterpret_cast<const unsigned*>(&o);
+              unsigned res[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(pv[k] << 16) + __uint_as_float(po[k] << 16);
+                const float hi = __uint_as_float(pv[k] & 0xffff0000u) + __uint_as_float(po[k] & 0xffff0000u);
+                res[k] = pack_bf16x2(lo, hi);
+              }
+              v = make_uint4(res[0], res[1], res[2], res[3]);
+            }
+            *reinterpret_cast<uint4*>(a.Y + off) = v;
+          }
+        }
+      }
+    }
+    // the counted waits of the next tile's first steps may skip ESTORES stores only if every wave certainly issued them
+    after_epilogue = (more && full) ? 1 : 0;
+  }
+#undef YV1_MFMA_BLOCK_P
+#undef YV1_SET_TAP_P
+#undef YV1_SET_TILE_P
+#undef YV1_ISSUE_P
+
+  if (a.stats) {
+    // one partial row per workgroup: reduce the two half-waves, then the WM waves that share a column range
+    __syncthreads();                                           // every wave is done with the ring and its staging area
+    float* red = reinterpret_cast<float*>(smem);               // [WM][2][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = st_s[j], ss = st_ss[j];
+      s += __shfl_xor(s, 32, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lh == 0) {
+        const int c = wn * CW + j * 32 + l31;
+        red[(wm * 2 + 0) * BN + c] = s;
+        red[(wm * 2 + 1) * BN + c] = ss;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s += red[(w * 2 + 0) * BN + tid];
+        ss += red[(w * 2 + 1) * BN + tid];
+      }
+      float* o = a.stats + (size_t)slot * 2 * a.Cout + n0 + tid;
+      o[0] = s;
+      o[a.Cout] = ss;
+    }
+  }
+}
+
+// workgroups the chip holds at once for a k_conv_ps instantiation (CUs x workgroups per CU by LDS / launch bounds)
+int ps_capacity(int wgs_per_cu) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+    else
+      ncu = 256;                                               // MI355X
+  }
+  return ncu * wgs_per_cu;
+}
+
+// pixel-tile slots per column tile for a persistent launch: as many workgroups as the chip holds, at most one per tile
+int ps_slots(int MT, int NT, int bm, int bn, int bk, int nst) {
+  const int lds = nst * (bm + bn) * bk * 2;
+  int per_cu = (160 * 1024) / lds;
+  const int cap = (bm * bn <= 128 * 128) ? 3 : 2;
+  per_cu = per_cu < 1 ? 1 : (per_cu < cap ? per_cu : cap);     // == ps_wgs_per_cu<>()
+  int s = ps_capacity(per_cu) / NT;
+  if (s < 1) s = 1;
+  return s < MT ? s : MT;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NST>
+int launch_ps(ConvArgs& a, hipStream_t stream) {
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr size_t LDS = (size_t)NST * STAGE > (size_t)WM * 2 * BN * 4 ? (size_t)NST * STAGE : (size_t)WM * 2 * BN * 4;
+  a.MT = (a.M + BM - 1) / BM;
+  a.NT = a.Cout / BN;
+  a.slots = ps_slots(a.MT, a.NT, BM, BN, BK, NST);
+  const bool plain = !a.escale && !a.erelu && !a.AS && !a.ERES && !a.accumulate && a.os == 1;
+  {
+    const bool direct = a.R * a.S == 1 && a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0 && a.log2d == 0 &&
+                        a.P == a.IH && a.Q == a.IW;
+    yv1_cfg_note("k_conv_ps<%d,%d,%d,%d,%d,%d,%s>%s", BM, BN, BK, WM, WN, NST, plain ? "plain" : "generic", direct ? " direct" : "");
+  }
+  if (plain) {
+    auto kern = k_conv_ps<BM, BN, BK, WM, WN, NST, true>;
+    if (LDS > 64 * 1024) YV1_SET_MAX_LDS(kern, LDS);
+    hipLaunchKernelGGL(kern, dim3(a.slots * a.NT), dim3(WM * WN * 64), LDS, stream, a);
+  } else {
+    auto kern = k_conv_ps<BM, BN, BK, WM, WN, NST, false>;
+    if (LDS > 64 * 1024) YV1_SET_MAX_LDS(kern, LDS);
+    hipLaunchKernelGGL(kern, dim3(a.slots * a.NT), dim3(WM * WN * 64), LDS, stream, a);
+  }
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int NST>
 int launch_dma(ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
@@ -656,67 +1117,98 @@ int choose_cfg(int M, int Cout, int Cin, int* bn) {
   return 128;
 }
 
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// The kernel a convolution GEMM of this shape runs: kind 0 = k_conv_gemm (register-staged), 1 = k_conv_dma (LDS-DMA
+// ring, one tile per workgroup), 2 = k_conv_ps (LDS-DMA ring, persistent workgroups).  One function decides for
+// dispatch() and for yv1_conv2d_stats_rows(), which must agree on the number of statistic partial rows.
+struct ConvPlan { int kind, bm, bn, bk, nst; };
+
+ConvPlan plan_conv(int M, int Cout, int Cin, int taps) {
+  ConvPlan p;
+  static int dma = -1, fbk = -1, ps = -1;
+  if (dma < 0) {
+    dma = env_int("YV1_CONV_DMA", 1);       // 0: register-staged loop; 2/3/4: force a stage count
+    fbk = env_int("YV1_CONV_BK", 0);        // 32 | 64: force the K-step
+    ps = env_int("YV1_CONV_PS", 1);         // 0: one tile per workgroup (k_conv_dma) instead of persistent workgroups
+  }
+  p.bm = choose_cfg(M, Cout, Cin, &p.bn);
+  const bool c64 = (Cin % 64) == 0;
+  if (!dma || !(c64 || p.bn != 32) || (p.bm == 128 && p.bn == 32 && !c64)) {
+    // register-staged loop.  BK: 64 halves the barriers per MAC but its 64 KB of LDS allows only 2 workgroups per CU;
+    // measured per layer: BK 32 on the large, bandwidth-bound feature maps, BK 64 on the deep compute-bound layers
+    bool k64 = c64 && M < 150000;
+    if (fbk == 32) k64 = false;
+    if (fbk == 64) k64 = c64;
+    p.kind = 0; p.bk = k64 ? 64 : 32; p.nst = 2;
+    return p;
+  }
+  // LDS-DMA ring.  Measured per layer (tools/bench_conv.py, N=64): BK 32 with three stages (48 KB, 3 workgroups/CU, two
+  // K-steps in flight) wins on the bandwidth-bound feature maps; BK 64 with two stages (64 KB, 2 workgroups/CU) on the deep
+  // 3x3 / Cin >= 1024 layers; the 64x64 tiles of the 7x7 maps take BK 64 with three stages.
+  bool d64 = c64 && ((taps > 1 && M < 250000) || (Cin >= 1024 && M < 150000));
+  int nst = d64 ? 2 : 3;
+  if (p.bm == 64 && c64) { d64 = true; nst = 3; }
+  if (fbk == 32) { d64 = false; if (dma == 1) nst = 3; }
+  if (fbk == 64 && c64) { d64 = true; if (dma == 1) nst = (p.bm == 64) ? 3 : 2; }
+  if (dma >= 2) nst = dma > 4 ? 4 : dma;
+  if (d64 && nst > 3) nst = 3;
+  p.kind = ps ? 2 : 1;
+  // one 256-wide column tile when it covers all of Cout: the gathered A rows are then fetched L2 -> LDS once
+  // instead of twice (these loops are bound by that bandwidth); 9 % on 256->256 3x3 @28, 3 % on 1024->256
+  if (dma == 1 && p.bm == 128 && p.bn == 128 && Cout == 256 && M <= 60000 && (taps > 1 || Cin >= 1024)) {
+    p.bn = 256; p.bk = 32; p.nst = 3;
+    return p;
+  }
+  if (p.bm == 128 && p.bn == 32) { p.bk = 64; p.nst = 3; return p; }      // DenseNet growth convs (c64 here)
+  p.bk = d64 ? 64 : 32;
+  p.nst = d64 ? (nst >= 3 ? 3 : 2) : (nst >= 4 ? 4 : (nst == 3 ? 3 : 2));
+  if (p.kind == 2 && p.nst > 3) p.kind = 1;                                // four-stage rings: tuning builds only
+  return p;
+}
+
 int dispatch(ConvArgs& a, hipStream_t stream) {
   if (a.Cin % 32 || a.Cout % 32 || a.ldx % 8 || a.ldy % 8) return YV1_ERR_UNSUPPORTED;
   {
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("YV1_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = env_int("YV1_CONV_DBG", 0);
     a.dbg = dbg;
   }
-  // BK: 64 halves the barriers per MAC but its 64 KB of LDS allows only 2 workgroups per CU; BK 32 (32 KB, 4 per
-  // CU) overlaps the load and MFMA phases of more workgroups.  Measured per layer: BK 32 wins on the large,
-  // bandwidth-bound feature maps (56x56 and up), BK 64 on the deep compute-bound layers.
-  bool k64 = (a.Cin % 64) == 0 && a.M < 150000;
-  {
-    static int forced = -1;                  // tuning: YV1_CONV_BK=32|64 overrides the choice
-    if (forced < 0) { const char* e = getenv("YV1_CONV_BK"); forced = e ? atoi(e) : 0; }
-    if (forced == 32) k64 = false;
-    if (forced == 64) k64 = (a.Cin % 64) == 0;
+  const ConvPlan p = plan_conv(a.M, a.Cout, a.Cin, a.R * a.S);
+  if (p.kind == 0) {
+    const bool k64 = p.bk == 64;
+    if (p.bm == 128 && p.bn == 128) return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
+    if (p.bm == 128 && p.bn == 64) return k64 ? launch<128, 64, 64, 2, 2>(a, stream) : launch<128, 64, 32, 2, 2>(a, stream);
+    if (p.bm == 64 && p.bn == 64) return k64 ? launch<64, 64, 64, 2, 2>(a, stream) : launch<64, 64, 32, 2, 2>(a, stream);
+    if (p.bm == 128 && p.bn == 32) return k64 ? launch<128, 32, 64, 4, 1>(a, stream) : launch<128, 32, 32, 4, 1>(a, stream);
+    return YV1_ERR_UNSUPPORTED;
   }
-  int bn = 0;
-  const int bm = choose_cfg(a.M, a.Cout, a.Cin, &bn);
-  {
-    // Default main loop: the LDS-DMA ring (k_conv_dma).  Measured per layer (tools/bench_conv.py, N=64): BK 32 with three
-    // stages (48 KB, 3 workgroups/CU, two K-steps in flight) wins on the bandwidth-bound feature maps; BK 64 with two
-    // stages (64 KB, 2 workgroups/CU) on the deep 3x3 / Cin >= 1024 layers; the 64x64 tiles of the 7x7 maps take BK 64
-    // with three stages.  YV1_CONV_DMA=0 selects the register-staged loop (k_conv_gemm), 2/3/4 force a stage count.
-    static int dma = -1;
-    if (dma < 0) { const char* e = getenv("YV1_CONV_DMA"); dma = e ? atoi(e) : 1; }
-    if (dma) {
-      const bool c64 = (a.Cin % 64) == 0;
-      bool d64 = c64 && ((a.R * a.S > 1 && a.M < 250000) || (a.Cin >= 1024 && a.M < 150000));
-      int nst = d64 ? 2 : 3;
-      if (bm == 64 && c64) { d64 = true; nst = 3; }
-      {
-        static int fbk = -1;
-        if (fbk < 0) { const char* e = getenv("YV1_CONV_BK"); fbk = e ? atoi(e) : 0; }
-        if (fbk == 32) { d64 = false; if (dma == 1) nst = 3; }
-        if (fbk == 64 && c64) { d64 = true; if (dma == 1) nst = (bm == 64) ? 3 : 2; }
-      }
-      if (dma >= 2) nst = dma > 4 ? 4 : dma;
-      if (d64 && nst > 3) nst = 3;
-      // one 256-wide column tile when it covers all of Cout: the gathered A rows are then fetched L2 -> LDS once
-      // instead of twice (these loops are bound by that bandwidth); 9 % on 256->256 3x3 @28, 3 % on 1024->256
-      if (dma == 1 && bm == 128 && bn == 128 && a.Cout == 256 && a.M <= 60000 && (a.R * a.S > 1 || a.Cin >= 1024))
-        return launch_dma<128, 256, 32, 2, 2, 3>(a, stream);
-#define YV1_DMA_CASE(BM_, BN_)                                                                                   \
-      if (bm == BM_ && bn == BN_) {                                                                              \
-        if (d64) return nst >= 3 ? launch_dma<BM_, BN_, 64, 2, 2, 3>(a, stream) : launch_dma<BM_, BN_, 64, 2, 2, 2>(a, stream); \
-        return nst >= 4 ? launch_dma<BM_, BN_, 32, 2, 2, 4>(a, stream)                                           \
-                        : (nst == 3 ? launch_dma<BM_, BN_, 32, 2, 2, 3>(a, stream) : launch_dma<BM_, BN_, 32, 2, 2, 2>(a, stream)); \
-      }
-      if (bm == 128 && bn == 32 && c64) return launch_dma<128, 32, 64, 4, 1, 3>(a, stream);   // DenseNet growth convs
-      YV1_DMA_CASE(128, 256)
-      YV1_DMA_CASE(128, 128)
-      YV1_DMA_CASE(128, 64)
-      YV1_DMA_CASE(64, 64)
-#undef YV1_DMA_CASE
-    }
+#define YV1_RING_CASE(BM_, BN_, BK_, WM_, WN_, NST_)                                                             \
+  if (p.bm == BM_ && p.bn == BN_ && p.bk == BK_ && p.nst == NST_)                                                \
+    return p.kind == 2 ? launch_ps<BM_, BN_, BK_, WM_, WN_, NST_>(a, stream) : launch_dma<BM_, BN_, BK_, WM_, WN_, NST_>(a, stream);
+  YV1_RING_CASE(128, 256, 32, 2, 2, 3)
+  YV1_RING_CASE(128, 32, 64, 4, 1, 3)
+  YV1_RING_CASE(128, 128, 32, 2, 2, 3)
+  YV1_RING_CASE(128, 128, 32, 2, 2, 2)
+  YV1_RING_CASE(128, 128, 64, 2, 2, 2)
+  YV1_RING_CASE(128, 128, 64, 2, 2, 3)
+  YV1_RING_CASE(128, 64, 32, 2, 2, 3)
+  YV1_RING_CASE(128, 64, 32, 2, 2, 2)
+  YV1_RING_CASE(128, 64, 64, 2, 2, 2)
+  YV1_RING_CASE(128, 64, 64, 2, 2, 3)
+  YV1_RING_CASE(64, 64, 32, 2, 2, 3)
+  YV1_RING_CASE(64, 64, 32, 2, 2, 2)
+  YV1_RING_CASE(64, 64, 64, 2, 2, 2)
+  YV1_RING_CASE(64, 64, 64, 2, 2, 3)
+#undef YV1_RING_CASE
+  if (p.nst == 4) {                                                       // tuning builds (YV1_CONV_DMA=4)
+    if (p.bm == 128 && p.bn == 128) return launch_dma<128, 128, 32, 2, 2, 4>(a, stream);
+    if (p.bm == 128 && p.bn == 64) return launch_dma<128, 64, 32, 2, 2, 4>(a, stream);
+    if (p.bm == 64 && p.bn == 64) return launch_dma<64, 64, 32, 2, 2, 4>(a, stream);
   }
-  if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
-  if (bm == 128 && bn == 64) return k64 ? launch<128, 64, 64, 2, 2>(a, stream) : launch<128, 64, 32, 2, 2>(a, stream);
-  if (bm == 64 && bn == 64) return k64 ? launch<64, 64, 64, 2, 2>(a, stream) : launch<64, 64, 32, 2, 2>(a, stream);
-  if (bm == 128 && bn == 32) return k64 ? launch<128, 32, 64, 4, 1>(a, stream) : launch<128, 32, 32, 4, 1>(a, stream);
   return YV1_ERR_UNSUPPORTED;
 }
 
@@ -900,11 +1392,13 @@ extern "C" int yv1_conv2d_dgrad_add_masked_nhwc_bf16(const void* dy, const void*
   return dispatch(a, stream);
 }
 
-extern "C" int yv1_conv2d_stats_rows(int M, int Cout, int Cin) {
-  // number of partial rows the forward kernel writes for this shape (same tile choice as dispatch())
-  int bn = 0;
-  const int bm = choose_cfg(M, Cout, Cin, &bn);
-  return (M + bm - 1) / bm;
+extern "C" int yv1_conv2d_stats_rows(int M, int Cout, int Cin, int k) {
+  // number of partial rows the forward kernel writes for this shape (same plan as dispatch()): one per pixel tile, or
+  // one per workgroup slot for the persistent kernel
+  const ConvPlan p = plan_conv(M, Cout, Cin, k * k);
+  const int MT = (M + p.bm - 1) / p.bm;
+  if (p.kind == 2) return ps_slots(MT, Cout / p.bn, p.bm, p.bn, p.bk, p.nst);
+  return MT;
 }
 
 extern "C" int yv1_pack_input_nhwc4(const float* x_nchw, void* y, int N, int H, int W, hipStream_t stream) {

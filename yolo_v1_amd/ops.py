@@ -142,7 +142,7 @@ def conv_fwd(x, w, y, want_stats=True):
     M = y.npix
     stats = None
     if want_stats:
-        rows = lib().yv1_conv2d_stats_rows(M, w.Opad, w.Ipad)
+        rows = lib().yv1_conv2d_stats_rows(M, w.Opad, w.Ipad, w.k)
         stats = _f32(rows * 2 * w.Opad, dev).view(rows, 2, w.Opad)
     check(lib().yv1_conv2d_fwd_nhwc_bf16(x.p, ptr(w.fwd), y.p, x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, y.ld, w.k, w.stride,
                                          w.pad, ptr(stats), stream_ptr(dev)), "yv1_conv2d_fwd_nhwc_bf16")
