@@ -67,6 +67,7 @@ struct ConvArgs {
   int M;
   int MT, NT;
   int slots = 0;       // k_conv_ps: workgroups per column tile; workgroup (slot, nt) walks the pixel tiles slot, slot+slots, ...
+  int stagger = 0, ncu = 256;   // tuning: workgroup b starts (b / ncu) * stagger * ~0.4 us late (co-resident workgroups out of phase)
   int dbg = 0;         // tuning only: bit0 skip the in-loop global loads / LDS stores, bit1 skip the MFMA block
 };
 
@@ -611,7 +612,7 @@ template <int BM, int BN, int BK, int NST>
 constexpr int ps_wgs_per_cu() {
   constexpr int lds = NST * (BM + BN) * BK * 2;
   constexpr int by_lds = (160 * 1024) / lds;
-  constexpr int cap = BM * BN <= 128 * 128 ? 3 : 2;
+  constexpr int cap = BM * BN <= 128 * 64 ? 4 : (BM * BN <= 128 * 128 ? 3 : 2);    // VGPR budget: 128 / 168 / 256 per lane
   return by_lds < 1 ? 1 : (by_lds < cap ? by_lds : cap);
 }
 
@@ -653,6 +654,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
   }
   const int n0 = nt * BN;
   const int S = a.slots;
+  if (a.stagger) {
+    const int g = blockIdx.x / a.ncu;
+    for (int i = 0; i < g * a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
 
   const int cslot = tid % CPR, rrow = tid / CPR;
   const int lchunk = swz<BK>(rrow, cslot);
@@ -1000,8 +1005,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
   }
 }
 
-// workgroups the chip holds at once for a k_conv_ps instantiation (CUs x workgroups per CU by LDS / launch bounds)
-int ps_capacity(int wgs_per_cu) {
+int env_int(const char* name, int dflt);
+
+// CUs of the current device (cached)
+int ps_ncu() {
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -1011,18 +1018,49 @@ int ps_capacity(int wgs_per_cu) {
     else
       ncu = 256;                                               // MI355X
   }
-  return ncu * wgs_per_cu;
+  return ncu;
+}
+
+// Workgroups of one k_conv_ps instantiation that are resident per CU: the smaller of what its LDS request and its
+// ALLOCATED registers admit (512 VGPRs per SIMD lane, granule 8; a 256-thread workgroup is one wave per SIMD).
+// launch_bounds is only a hint to the register allocator -- the generic-epilogue forms exceed the 128-VGPR budget of four
+// workgroups per CU -- so the grid is sized from the compiled kernel, not from the hint: a persistent grid larger than
+// what is resident would run its surplus workgroups as a second, mostly idle round.
+template <int BM, int BN, int BK, int WM, int WN, int NST, bool PLAIN>
+int ps_resident_per_cu() {
+  static int cached = 0;
+  if (cached) return cached;
+  constexpr int lds = NST * (BM + BN) * BK * 2;
+  int by_lds = (160 * 1024) / lds;
+  if (by_lds < 1) by_lds = 1;
+  int by_regs = ps_wgs_per_cu<BM, BN, BK, NST>();
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, (const void*)k_conv_ps<BM, BN, BK, WM, WN, NST, PLAIN>) == hipSuccess && attr.numRegs > 0) {
+    const int alloc = (attr.numRegs + 7) / 8 * 8;
+    by_regs = 512 / alloc;
+    if (by_regs > 8) by_regs = 8;
+    if (by_regs < 1) by_regs = 1;
+  }
+  int r = by_lds < by_regs ? by_lds : by_regs;
+  if (r > 4) r = 4;                                            // more than 16 waves per CU buys nothing here
+  cached = r;
+  return r;
 }
 
 // pixel-tile slots per column tile for a persistent launch: as many workgroups as the chip holds, at most one per tile
-int ps_slots(int MT, int NT, int bm, int bn, int bk, int nst) {
-  const int lds = nst * (bm + bn) * bk * 2;
-  int per_cu = (160 * 1024) / lds;
-  const int cap = (bm * bn <= 128 * 128) ? 3 : 2;
-  per_cu = per_cu < 1 ? 1 : (per_cu < cap ? per_cu : cap);     // == ps_wgs_per_cu<>()
-  int s = ps_capacity(per_cu) / NT;
+int ps_slots(int MT, int NT, int per_cu) {
+  static int reserve = -1;                                     // tuning: leave this many workgroup slots per CU to other streams
+  if (reserve < 0) reserve = env_int("YV1_PS_RESERVE", 0);
+  if (per_cu - reserve >= 1) per_cu -= reserve;
+  int s = ps_ncu() * per_cu / NT;
   if (s < 1) s = 1;
-  return s < MT ? s : MT;
+  if (s >= MT) return MT;
+  static int balance = -1;
+  if (balance < 0) balance = env_int("YV1_PS_BALANCE", 0);
+  if (!balance) return s;
+  // balanced variant (measured: slower -- fewer workgroups in flight cost more than the ragged last round)
+  const int k = (MT + s - 1) / s;
+  return (MT + k - 1) / k;
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NST>
@@ -1031,8 +1069,14 @@ int launch_ps(ConvArgs& a, hipStream_t stream) {
   constexpr size_t LDS = (size_t)NST * STAGE > (size_t)WM * 2 * BN * 4 ? (size_t)NST * STAGE : (size_t)WM * 2 * BN * 4;
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
-  a.slots = ps_slots(a.MT, a.NT, BM, BN, BK, NST);
-  const bool plain = !a.escale && !a.erelu && !a.AS && !a.ERES && !a.accumulate && a.os == 1;
+    const bool plain = !a.escale && !a.erelu && !a.AS && !a.ERES && !a.accumulate && a.os == 1;
+  {
+    static int stagger = -1;
+    if (stagger < 0) stagger = env_int("YV1_PS_STAGGER", 0);
+    a.stagger = stagger; a.ncu = ps_ncu();
+  }
+  a.slots = ps_slots(a.MT, a.NT, plain ? ps_resident_per_cu<BM, BN, BK, WM, WN, NST, true>()
+                                       : ps_resident_per_cu<BM, BN, BK, WM, WN, NST, false>());
   {
     const bool direct = a.R * a.S == 1 && a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0 && a.log2d == 0 &&
                         a.P == a.IH && a.Q == a.IW;
@@ -1157,6 +1201,14 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps) {
   if (dma >= 2) nst = dma > 4 ? 4 : dma;
   if (d64 && nst > 3) nst = 3;
   p.kind = ps ? 2 : 1;
+  // Persistent workgroups (k_conv_ps) are assigned their tiles statically; measured per layer at batch 64
+  // (gpurun_out/r2f tables, same box, interleaved): 3-17 % faster wherever a tile is short (small K, wide output: the next
+  // tile's loads fly under the epilogue) or compute-heavy, but 8-14 % slower on the 112x112 maps with <= 128 output
+  // channels and on 512 -> 256 @56: those stream > 400 MB at the HBM rate already, their tiles take the same time with a
+  // few workgroups running as with all of them, and 6272 (1568) tiles over 768-1024 (384) resident workgroups leave a
+  // ragged last round that one-tile-per-workgroup launches fill dynamically.
+  if (ps == 1 && ((M >= 600000 && Cout <= 128 && Cin * taps >= 256) || (M >= 150000 && M < 600000 && Cout == 256 && Cin >= 512 && taps == 1)))
+    p.kind = 1;
   // one 256-wide column tile when it covers all of Cout: the gathered A rows are then fetched L2 -> LDS once
   // instead of twice (these loops are bound by that bandwidth); 9 % on 256->256 3x3 @28, 3 % on 1024->256
   if (dma == 1 && p.bm == 128 && p.bn == 128 && Cout == 256 && M <= 60000 && (taps > 1 || Cin >= 1024)) {
@@ -1169,6 +1221,23 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps) {
   if (p.kind == 2 && p.nst > 3) p.kind = 1;                                // four-stage rings: tuning builds only
   return p;
 }
+
+// every (tile, K-step, stage count) the ring kernels are instantiated for
+#define YV1_RING_CASES                 \
+  YV1_RING_CASE(128, 256, 32, 2, 2, 3) \
+  YV1_RING_CASE(128, 32, 64, 4, 1, 3)  \
+  YV1_RING_CASE(128, 128, 32, 2, 2, 3) \
+  YV1_RING_CASE(128, 128, 32, 2, 2, 2) \
+  YV1_RING_CASE(128, 128, 64, 2, 2, 2) \
+  YV1_RING_CASE(128, 128, 64, 2, 2, 3) \
+  YV1_RING_CASE(128, 64, 32, 2, 2, 3)  \
+  YV1_RING_CASE(128, 64, 32, 2, 2, 2)  \
+  YV1_RING_CASE(128, 64, 64, 2, 2, 2)  \
+  YV1_RING_CASE(128, 64, 64, 2, 2, 3)  \
+  YV1_RING_CASE(64, 64, 32, 2, 2, 3)   \
+  YV1_RING_CASE(64, 64, 32, 2, 2, 2)   \
+  YV1_RING_CASE(64, 64, 64, 2, 2, 2)   \
+  YV1_RING_CASE(64, 64, 64, 2, 2, 3)
 
 int dispatch(ConvArgs& a, hipStream_t stream) {
   if (a.Cin % 32 || a.Cout % 32 || a.ldx % 8 || a.ldy % 8) return YV1_ERR_UNSUPPORTED;
@@ -1189,20 +1258,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
 #define YV1_RING_CASE(BM_, BN_, BK_, WM_, WN_, NST_)                                                             \
   if (p.bm == BM_ && p.bn == BN_ && p.bk == BK_ && p.nst == NST_)                                                \
     return p.kind == 2 ? launch_ps<BM_, BN_, BK_, WM_, WN_, NST_>(a, stream) : launch_dma<BM_, BN_, BK_, WM_, WN_, NST_>(a, stream);
-  YV1_RING_CASE(128, 256, 32, 2, 2, 3)
-  YV1_RING_CASE(128, 32, 64, 4, 1, 3)
-  YV1_RING_CASE(128, 128, 32, 2, 2, 3)
-  YV1_RING_CASE(128, 128, 32, 2, 2, 2)
-  YV1_RING_CASE(128, 128, 64, 2, 2, 2)
-  YV1_RING_CASE(128, 128, 64, 2, 2, 3)
-  YV1_RING_CASE(128, 64, 32, 2, 2, 3)
-  YV1_RING_CASE(128, 64, 32, 2, 2, 2)
-  YV1_RING_CASE(128, 64, 64, 2, 2, 2)
-  YV1_RING_CASE(128, 64, 64, 2, 2, 3)
-  YV1_RING_CASE(64, 64, 32, 2, 2, 3)
-  YV1_RING_CASE(64, 64, 32, 2, 2, 2)
-  YV1_RING_CASE(64, 64, 64, 2, 2, 2)
-  YV1_RING_CASE(64, 64, 64, 2, 2, 3)
+  YV1_RING_CASES
 #undef YV1_RING_CASE
   if (p.nst == 4) {                                                       // tuning builds (YV1_CONV_DMA=4)
     if (p.bm == 128 && p.bn == 128) return launch_dma<128, 128, 32, 2, 2, 4>(a, stream);
@@ -1397,7 +1453,15 @@ extern "C" int yv1_conv2d_stats_rows(int M, int Cout, int Cin, int k) {
   // one per workgroup slot for the persistent kernel
   const ConvPlan p = plan_conv(M, Cout, Cin, k * k);
   const int MT = (M + p.bm - 1) / p.bm;
-  if (p.kind == 2) return ps_slots(MT, Cout / p.bn, p.bm, p.bn, p.bk, p.nst);
+  if (p.kind == 2) {
+    int per_cu = 0;                                            // statistics are written by the PLAIN (training) form only
+#define YV1_RING_CASE(BM_, BN_, BK_, WM_, WN_, NST_)                                                             \
+    if (p.bm == BM_ && p.bn == BN_ && p.bk == BK_ && p.nst == NST_) per_cu = ps_resident_per_cu<BM_, BN_, BK_, WM_, WN_, NST_, true>();
+    YV1_RING_CASES
+#undef YV1_RING_CASE
+    if (!per_cu) return MT;
+    return ps_slots(MT, Cout / p.bn, per_cu);
+  }
   return MT;
 }
 
