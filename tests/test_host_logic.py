@@ -84,7 +84,8 @@ def _gloo_worker(rank, world, port, q):
     sync2.start([(params[0], params[0].grad)])
     sync2.reduce_all([(p, p.grad) for p in params[1:]])
     second = [p.grad.clone() for p in params]
-    q.put((rank, [g.clone() for g in grads], first, sync.buckets_issued, second, sync2.buckets_issued))
+    tonp = lambda ts: [t.detach().contiguous().numpy().copy() for t in ts]      # numpy, not tensors: a tensor in an mp.Queue
+    q.put((rank, tonp(grads), tonp(first), sync.buckets_issued, tonp(second), sync2.buckets_issued))   # needs the sender alive
     dist.destroy_process_group()
 
 
@@ -100,6 +101,8 @@ def test_gradsync_gloo_world2_averages_into_param_grad():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    res = [(r, [torch.from_numpy(v) for v in g], [torch.from_numpy(v) for v in o], nb, [torch.from_numpy(v) for v in s_], nc)
+           for (r, g, o, nb, s_, nc) in res]
     (_, g0, out0, nb0, sec0, nc0), (_, g1, out1, nb1, sec1, nc1) = res
     assert nb0 >= 2 and nb0 == nb1 and nc0 == nc1 == 2
     for a, b, o0, o1, s0, s1 in zip(g0, g1, out0, out1, sec0, sec1):

@@ -406,7 +406,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NST>
-__global__ void __launch_bounds__(WM * WN * 64, (BM * BN <= 128 * 128 ? 3 : 2)) k_conv_dma(ConvArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128 * 128 ? 3 : 2))) k_conv_dma(ConvArgs a) {
   constexpr int NTH = WM * WN * 64;
   constexpr int CPR = BK / 8;
   constexpr int RPP = NTH / CPR;                       // rows per pass (one pass = one DMA instruction per wave)
@@ -612,7 +612,9 @@ template <int BM, int BN, int BK, int NST>
 constexpr int ps_wgs_per_cu() {
   constexpr int lds = NST * (BM + BN) * BK * 2;
   constexpr int by_lds = (160 * 1024) / lds;
-  constexpr int cap = BM * BN <= 128 * 64 ? 4 : (BM * BN <= 128 * 128 ? 3 : 2);    // VGPR budget: 128 / 168 / 256 per lane
+  // VGPR budget per lane: 128 / 168 / 256 for the four-wave tiles; the eight-wave 256-row tiles (two waves per SIMD and
+  // workgroup) get 256 (256x256: 128 accumulators) or 128 (256x128: 64 accumulators, two workgroups per CU)
+  constexpr int cap = BM == 256 ? 1 : (BM * BN <= 128 * 64 ? 4 : (BM * BN <= 128 * 128 ? 3 : 2));
   return by_lds < 1 ? 1 : (by_lds < cap ? by_lds : cap);
 }
 
@@ -621,7 +623,14 @@ constexpr int ps_wgs_per_cu() {
 // compiler drain the LDS-DMA queue (hipcc waits vmcnt(0) for any VGPR-destination load while a DMA is in flight) and the
 // prefetch really flies under the epilogue; the generic form is correct with any epilogue but drains there.
 template <int BM, int BN, int BK, int WM, int WN, int NST, bool PLAIN>
-__global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>())) k_conv_ps(ConvArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>() * (WM * WN / 4))) k_conv_ps(ConvArgs a) {   // 2nd argument: waves per SIMD
+  // Ping-pong main loop for the eight-wave tiles (below): measured SLOWER than the one-barrier loop on every layer it was
+  // tried on (256->256 3x3 @28: 72.9 vs 69.2 us; four stages instead of three: no gain either) -- these loops are not
+  // bound by the matrix pipe idling at the barrier.  Kept behind -DYV1_CONV_PP=1 as the record of that experiment.
+#ifndef YV1_CONV_PP
+#define YV1_CONV_PP 0
+#endif
+  constexpr bool PP = YV1_CONV_PP && WM * WN == 8 && NST >= 3;
   constexpr int NTH = WM * WN * 64;
   constexpr int CPR = BK / 8;
   constexpr int RPP = NTH / CPR;
@@ -754,14 +763,33 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
       fb_off[j][ks] = A_BYTES + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16;
     }
   }
-#define YV1_MFMA_BLOCK_P(BASE_)                                                                                  \
-  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                            \
-    bf16x8 fa[TM], fb[TN];                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>((BASE_) + fa_off[i][ks]); \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>((BASE_) + fb_off[j][ks]); \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);                   \
+// One K-step.  The LDS-DMA of the step NST-1 ahead (ISSUE_: address VALU + ~60-180 issue cycles per instruction) goes
+// AFTER the first fragment reads, so it executes while those ds_reads are in flight instead of in front of them.  The
+// 256x256 tile (256-register budget) reads the fragments of BOTH 16-deep slices up front: its second slice's MFMAs then
+// do not wait for their own LDS round trip; the four-wave tiles cannot afford those 24-32 extra registers (measured:
+// spills or a lost wave per SIMD).
+#define YV1_STEP_P(BASE_, ISSUE_)                                                                                \
+  if constexpr (BM == 256 && BN == 256) {                                                                        \
+    bf16x8 fa[KS][TM], fb[KS][TN];                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>((BASE_) + fa_off[i][ks]); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>((BASE_) + fb_off[j][ks]); \
+    }                                                                                                            \
+    ISSUE_;                                                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                            \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                           \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);         \
+  } else {                                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
+      bf16x8 fa[TM], fb[TN];                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>((BASE_) + fa_off[i][ks]); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>((BASE_) + fb_off[j][ks]); \
+      if (ks == 0) { ISSUE_; }                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                           \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);                 \
+    }                                                                                                            \
   }
 
   // BatchNorm statistics of this workgroup's column tile, summed over all its pixel tiles (lane = channel, see below)
@@ -793,46 +821,107 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    int kt = 0;
-    {
-      const int n_main = nk - (NST - 1);
-      for (; kt + NST <= n_main; kt += NST) {
-#pragma unroll
-        for (int c = 0; c < NST; ++c) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads / staging reads complete before the barrier
-          // the first NST-1 steps after an epilogue: its stores are younger than the step waited for, older than the
-          // steps issued since -- leave them in flight
-          if (kt == 0 && c < NST - 1 && after_epilogue) wait_vmcnt<(NST - 2) * LPS + ESTORES>();
-          else wait_vmcnt<(NST - 2) * LPS>();
-          __builtin_amdgcn_s_barrier();
-          YV1_ISSUE_P((c + NST - 1) % NST);
-          YV1_MFMA_BLOCK_P(smem + c * STAGE);
+    if constexpr (PP) {
+      // ---- ping-pong main loop (eight waves = two groups of four; waves w and w+4 share a SIMD) -------------------
+      // A K-step is two phases separated by barriers:  R = fragment reads of the step + LDS-DMA issue of the step NST-1
+      // ahead,  M = its 16 MFMAs.  Group 1 runs ONE barrier behind group 0 (an extra s_barrier on entry, one for group 0
+      // on exit), so on every SIMD one wave is in M while the other is in R: the matrix pipe always has a wave with its
+      // operands in registers, and the ds_reads / DMA issue / barrier latency of a step hide under the other group's
+      // MFMAs (the one-barrier loop below idles the pipe for all of that, every step, on every SIMD at once).
+      // Rules that keep the staggered groups safe (each wave, before the barrier X that ends ITS phase R of step k):
+      //   * s_waitcnt lgkmcnt(0): its reads of stage k are complete -> when the partner barrier releases the other
+      //     group into its next phase R, the stage that phase refills (the one read a step ago) is quiescent;
+      //   * counted vmcnt for ITS pieces of step k+1: the other group's pass of this barrier is its entry to reading
+      //     step k+1 (group 0), or the step is read one barrier later (group 1) -- either way everyone's pieces landed.
+      const int grp = wid >> 2;
+      {
+        const int younger = min(NST - 2, nk - 1);              // prefetched steps behind step 0
+        if (after_epilogue) {
+          if (younger >= 2) wait_vmcnt<2 * LPS + ESTORES>(); else if (younger == 1) wait_vmcnt<LPS + ESTORES>(); else wait_vmcnt<ESTORES>();
+        } else {
+          if (younger >= 2) wait_vmcnt<2 * LPS>(); else if (younger == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
         }
       }
-    }
-    int cur = 0, nxt = NST - 1;
-    for (; kt < nk; ++kt) {
-      const int younger = min(nk - 1 - kt, NST - 2);           // K-steps of THIS tile in flight behind step kt
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (after_epilogue && kt < NST - 1) {                    // step kt was prefetched before the epilogue: its stores are younger
-        if (younger >= 2) wait_vmcnt<2 * LPS + ESTORES>();
-        else if (younger == 1) wait_vmcnt<LPS + ESTORES>();
-        else wait_vmcnt<ESTORES>();
-      } else {
-        if (younger >= 2) wait_vmcnt<2 * LPS>();
-        else if (younger == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staging reads of the previous epilogue
+      if (grp == 1) __builtin_amdgcn_s_barrier();
+      int cur = 0, nxt = NST - 1;
+      for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();                          // Y: stage cur landed for everyone, stage nxt quiescent
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* base = smem + cur * STAGE;
+        bf16x8 fa[KS][TM], fb[KS][TN];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(base + fa_off[i][ks]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(base + fb_off[j][ks]);
+        }
+        if (kt + NST - 1 < nk) YV1_ISSUE_P(nxt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads complete before X (and cannot sink below it)
+        if (kt + 1 < nk) {
+          const int younger = min(NST - 2, nk - 2 - kt);       // issued steps behind step kt+1
+          if (after_epilogue && kt + 1 <= NST - 2) {           // step kt+1 was prefetched before the epilogue's stores
+            if (younger >= 2) wait_vmcnt<2 * LPS + ESTORES>(); else if (younger == 1) wait_vmcnt<LPS + ESTORES>(); else wait_vmcnt<ESTORES>();
+          } else {
+            if (younger >= 2) wait_vmcnt<2 * LPS>(); else if (younger == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+          }
+        }
+        __builtin_amdgcn_s_barrier();                          // X
+        __builtin_amdgcn_sched_barrier(0);                     // keep the MFMAs below it
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
       }
+      // group 0's closing barrier pairs with group 1's last X: every read of every stage is complete, every DMA of this
+      // tile has been waited for -- the ring is free for the next tile's prefetch (group 1 still runs its last MFMAs)
+      if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else {
+      int kt = 0;
+      {
+        const int n_main = nk - (NST - 1);
+        for (; kt + NST <= n_main; kt += NST) {
+#pragma unroll
+          for (int c = 0; c < NST; ++c) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads / staging reads complete before the barrier
+            // the first NST-1 steps after an epilogue: its stores are younger than the step waited for, older than the
+            // steps issued since -- leave them in flight
+            if (kt == 0 && c < NST - 1 && after_epilogue) wait_vmcnt<(NST - 2) * LPS + ESTORES>();
+            else wait_vmcnt<(NST - 2) * LPS>();
+            __builtin_amdgcn_s_barrier();
+            YV1_STEP_P(smem + c * STAGE, YV1_ISSUE_P((c + NST - 1) % NST));
+          }
+        }
+      }
+      int cur = 0, nxt = NST - 1;
+      for (; kt < nk; ++kt) {
+        const int younger = min(nk - 1 - kt, NST - 2);           // K-steps of THIS tile in flight behind step kt
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (after_epilogue && kt < NST - 1) {                    // step kt was prefetched before the epilogue: its stores are younger
+          if (younger >= 2) wait_vmcnt<2 * LPS + ESTORES>();
+          else if (younger == 1) wait_vmcnt<LPS + ESTORES>();
+          else wait_vmcnt<ESTORES>();
+        } else {
+          if (younger >= 2) wait_vmcnt<2 * LPS>();
+          else if (younger == 1) wait_vmcnt<LPS>();
+          else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        YV1_STEP_P(smem + cur * STAGE, if (kt + NST - 1 < nk) YV1_ISSUE_P(nxt));
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
+      }
+      // every wave has finished reading the ring: the next tile's first K-steps may land in stages 0 .. NST-2 while the
+      // epilogue runs; stage NST-1 is the staging area
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kt + NST - 1 < nk) YV1_ISSUE_P(nxt);
-      YV1_MFMA_BLOCK_P(smem + cur * STAGE);
-      cur = cur + 1 == NST ? 0 : cur + 1;
-      nxt = nxt + 1 == NST ? 0 : nxt + 1;
     }
-    // every wave has finished reading the ring: the next tile's first K-steps may land in stages 0 .. NST-2 while the
-    // epilogue runs; stage NST-1 is the staging area
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     const bool more = mt + S < a.MT;
     if (more) {
 #pragma unroll
@@ -970,7 +1059,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
     // the counted waits of the next tile's first steps may skip ESTORES stores only if every wave certainly issued them
     after_epilogue = (more && full) ? 1 : 0;
   }
-#undef YV1_MFMA_BLOCK_P
+#undef YV1_STEP_P
 #undef YV1_SET_TAP_P
 #undef YV1_SET_TILE_P
 #undef YV1_ISSUE_P
@@ -1037,7 +1126,7 @@ int ps_resident_per_cu() {
   hipFuncAttributes attr;
   if (hipFuncGetAttributes(&attr, (const void*)k_conv_ps<BM, BN, BK, WM, WN, NST, PLAIN>) == hipSuccess && attr.numRegs > 0) {
     const int alloc = (attr.numRegs + 7) / 8 * 8;
-    by_regs = 512 / alloc;
+    by_regs = (512 / alloc) / (WM * WN / 4);                   // waves per SIMD / waves per SIMD of one workgroup
     if (by_regs > 8) by_regs = 8;
     if (by_regs < 1) by_regs = 1;
   }
@@ -1212,10 +1301,18 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps) {
   // one 256-wide column tile when it covers all of Cout: the gathered A rows are then fetched L2 -> LDS once
   // instead of twice (these loops are bound by that bandwidth); 9 % on 256->256 3x3 @28, 3 % on 1024->256
   if (dma == 1 && p.bm == 128 && p.bn == 128 && Cout == 256 && M <= 60000 && (taps > 1 || Cin >= 1024)) {
+    // persistent: one 256x256 tile per CU, eight waves of 128x64 (0.75 fragment reads per MFMA instead of 1, weights
+    // fetched once per 256 pixel rows), BK 32 in a three-stage ring (96 KB): measured +11-13 % over 128x256 on 256->256
+    // 3x3 @28 and on its stride-2 sibling, +9 % on 1024->256 (four stages, BK 64 and 256x128 / 128x256 eight-wave
+    // tiles were all slower; 196 tiles on 256 CUs is what caps this shape)
+    static int t256 = -1;
+    if (t256 < 0) t256 = env_int("YV1_CONV_T256", 1);
+    if (p.kind == 2 && t256 && M >= 256 * 128) { p.bm = 256; p.bn = 256; p.bk = 32; p.nst = 3; return p; }
     p.bn = 256; p.bk = 32; p.nst = 3;
     return p;
   }
   if (p.bm == 128 && p.bn == 32) { p.bk = 64; p.nst = 3; return p; }      // DenseNet growth convs (c64 here)
+  if (p.bm == 256 && p.bn == 256) { p.bk = 32; p.nst = 3; return p; }                            // forced (YV1_CONV_CFG) only
   p.bk = d64 ? 64 : 32;
   p.nst = d64 ? (nst >= 3 ? 3 : 2) : (nst >= 4 ? 4 : (nst == 3 ? 3 : 2));
   if (p.kind == 2 && p.nst > 3) p.kind = 1;                                // four-stage rings: tuning builds only
@@ -1237,7 +1334,8 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps) {
   YV1_RING_CASE(64, 64, 32, 2, 2, 3)   \
   YV1_RING_CASE(64, 64, 32, 2, 2, 2)   \
   YV1_RING_CASE(64, 64, 64, 2, 2, 2)   \
-  YV1_RING_CASE(64, 64, 64, 2, 2, 3)
+  YV1_RING_CASE(64, 64, 64, 2, 2, 3)   \
+  YV1_RING_CASE(256, 256, 32, 2, 4, 3)
 
 int dispatch(ConvArgs& a, hipStream_t stream) {
   if (a.Cin % 32 || a.Cout % 32 || a.ldx % 8 || a.ldy % 8) return YV1_ERR_UNSUPPORTED;
