@@ -261,8 +261,14 @@ class ResNet(HipBackbone):
         ops.conv_dgrad(dyh, wh, g)
         self._emit(grads, [self.bn_end.weight, self.bn_end.bias, self.layer6.weight])
 
-        for brec in reversed(rec["blocks"]):
-            g = self.block_backward(brec, g, grads, side)
+        # The side stream gets little of the chip while the main stream's kernels run and finishes its queue alone after
+        # them (trace: the main stream idles ~4 ms at the end of the backward).  The weight gradients of the LAST blocks of
+        # the backward (layer1, large maps: HBM-bound, ~120 us each) therefore go onto the main stream, which would
+        # otherwise wait for them anyway: both queues then end together.
+        inline = ops.SideStream(dev, enabled=False)
+        nblk = len(rec["blocks"])
+        for bi, brec in enumerate(reversed(rec["blocks"])):
+            g = self.block_backward(brec, g, grads, side if nblk - bi > self.wgrad_main_tail else inline)
             if self._phase_boundary is not None and brec[0] is boundary_blk:
                 side.join()
                 self._phase_boundary(grads)
@@ -272,7 +278,7 @@ class ResNet(HipBackbone):
         # max-pool backward gathered inside the BatchNorm backward: the pool-input gradient is never materialised
         dy0 = ops.new_act(N, y0.H, y0.W, 64, dev)
         grads[self.bn1.weight], grads[self.bn1.bias] = ops.bn_backward(g, y0, s0, self.bn1, dy0, 2, pool_idx=pidx)
-        grads[self.conv1.weight] = ops.stem_wgrad(xp, dy0, w0, H, W, side)
+        grads[self.conv1.weight] = ops.stem_wgrad(xp, dy0, w0, H, W, side if self.wgrad_main_tail == 0 else None)
         side.join()
         self._emit(grads, [self.bn1.weight, self.bn1.bias, self.conv1.weight])
         return grads

@@ -343,7 +343,9 @@ _SIDE_STREAMS = {}
 def _side_stream_for(device):
     key = torch.device(device).index
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+        import os
+        prio = int(os.environ.get("YV1_SIDE_PRIORITY", "0"))      # tuning: -1 = high priority for the weight-gradient stream
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device, priority=prio)
     return _SIDE_STREAMS[key]
 
 
