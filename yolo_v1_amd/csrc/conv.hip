@@ -592,6 +592,15 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128
   conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
 }
 
+// off ^ (ks << 5), computed where it is used: volatile asm so that the compiler does not hoist the KS variants of every
+// fragment offset out of the K loop into registers (slice 0 needs no instruction)
+__device__ __forceinline__ int frag_off(int off0, int ks) {
+  if (ks == 0) return off0;
+  int o;
+  asm volatile("v_xor_b32 %0, %1, %2" : "=v"(o) : "v"(ks << 5), "v"(off0));
+  return o;
+}
+
 // ---- persistent form of k_conv_dma ---------------------------------------------------------------------------
 // Same tiles, ring, swizzle and MFMA loop, but a workgroup owns ONE column tile (nt) and walks the pixel tiles
 // slot, slot + slots, slot + 2 slots ... of it:
@@ -749,19 +758,19 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
 
   const int l31 = lane & 31, lh = lane >> 5;
   constexpr int KS = BK / 16;
-  int fa_off[TM][KS], fb_off[TN][KS];
+  // fragment byte offsets of the first 16-deep slice; slice ks is the same offset with bits 5.. flipped by ks: the swizzled
+  // chunk (2 ks + lh) ^ key(row) equals (lh ^ key) ^ 2 ks, so  off(ks) = off(0) ^ (ks << 5)  -- one v_xor per read instead
+  // of KS registers per fragment row (what made the BK 64 forms spill or lose a wave per SIMD)
+  int fa_off0[TM], fb_off0[TN];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
+  for (int i = 0; i < TM; ++i) {
+    const int row = wm * (BM / WM) + i * 32 + l31;
+    fa_off0[i] = row * (BK * 2) + swz<BK>(row, lh) * 16;
+  }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row = wm * (BM / WM) + i * 32 + l31;
-      fa_off[i][ks] = row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = wn * (BN / WN) + j * 32 + l31;
-      fb_off[j][ks] = A_BYTES + row * (BK * 2) + swz<BK>(row, ks * 2 + lh) * 16;
-    }
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * (BN / WN) + j * 32 + l31;
+    fb_off0[j] = A_BYTES + row * (BK * 2) + swz<BK>(row, lh) * 16;
   }
 // One K-step.  The LDS-DMA of the step NST-1 ahead (ISSUE_: address VALU + ~60-180 issue cycles per instruction) goes
 // AFTER the first fragment reads, so it executes while those ds_reads are in flight instead of in front of them.  The
@@ -769,11 +778,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
 // do not wait for their own LDS round trip; the four-wave tiles cannot afford those 24-32 extra registers (measured:
 // spills or a lost wave per SIMD).
 #define YV1_STEP_P(BASE_, ISSUE_)                                                                                \
-  if constexpr (BM == 256 && BN == 256) {                                                                        \
+  if constexpr (BM == 256 && BN == 256 && KS <= 2) {                                                             \
     bf16x8 fa[KS][TM], fb[KS][TN];                                                                               \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>((BASE_) + fa_off[i][ks]); \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>((BASE_) + fb_off[j][ks]); \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>((BASE_) + frag_off(fa_off0[i], ks)); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>((BASE_) + frag_off(fb_off0[j], ks)); \
     }                                                                                                            \
     ISSUE_;                                                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                            \
@@ -783,8 +792,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
   } else {                                                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
       bf16x8 fa[TM], fb[TN];                                                                                     \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>((BASE_) + fa_off[i][ks]); \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>((BASE_) + fb_off[j][ks]); \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>((BASE_) + frag_off(fa_off0[i], ks)); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>((BASE_) + frag_off(fb_off0[j], ks)); \
       if (ks == 0) { ISSUE_; }                                                                                   \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                           \
@@ -853,9 +862,9 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(base + fa_off[i][ks]);
+          for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(base + frag_off(fa_off0[i], ks));
 #pragma unroll
-          for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(base + fb_off[j][ks]);
+          for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(base + frag_off(fb_off0[j], ks));
         }
         if (kt + NST - 1 < nk) YV1_ISSUE_P(nxt);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads complete before X (and cannot sink below it)
@@ -1303,7 +1312,7 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps) {
   if (dma == 1 && p.bm == 128 && p.bn == 128 && Cout == 256 && M <= 60000 && (taps > 1 || Cin >= 1024)) {
     // persistent: one 256x256 tile per CU, eight waves of 128x64 (0.75 fragment reads per MFMA instead of 1, weights
     // fetched once per 256 pixel rows), BK 32 in a three-stage ring (96 KB): measured +11-13 % over 128x256 on 256->256
-    // 3x3 @28 and on its stride-2 sibling, +9 % on 1024->256 (four stages, BK 64 and 256x128 / 128x256 eight-wave
+    // 3x3 @28 and on its stride-2 sibling, +9 % on 1024->256 (four stages, BK 64 in two stages, and 256x128 / 128x256 eight-wave
     // tiles were all slower; 196 tiles on 256 CUs is what caps this shape)
     static int t256 = -1;
     if (t256 < 0) t256 = env_int("YV1_CONV_T256", 1);
