@@ -94,7 +94,7 @@ RESNET50_S7_CONVS = [(64, 64, 1, 1, 112, 1), (64, 64, 3, 1, 112, 3), (64, 256, 1
 
 
 def conv_kernel_roofline(batch, device, iters=5):
-    """The dominant kernel family of the step -- the implicit-GEMM convolution (k_conv_dma: forward and data
+    """The dominant kernel family of the step -- the implicit-GEMM convolution (k_conv_ps / k_conv_dma: forward and data
     gradient of the 58 Bottleneck convolutions) -- on its own: every distinct layer shape launched ``iters`` times
     between HIP events on the launch stream, weighted by how often the step runs it.  Algorithmic flops / that time."""
     from yolo_v1_amd import ops
@@ -125,7 +125,8 @@ def conv_kernel_roofline(batch, device, iters=5):
             per_launch.append(us)
     n = 2 * sum(c[5] for c in RESNET50_S7_CONVS)
     tf = flops / t_us / 1e6
-    return {"name": "k_conv_dma: implicit-GEMM NHWC convolution, forward + data gradient of the Bottleneck convolutions",
+    return {"name": "k_conv_ps / k_conv_dma: implicit-GEMM NHWC convolution (LDS-DMA ring, persistent workgroups), forward + data "
+                    "gradient of the Bottleneck convolutions",
             "launches_per_step": n, "avg_launch_us": round(t_us / n, 1), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
             "note": "each distinct layer shape timed alone with HIP events (%d launches), weighted by its count in the "
