@@ -58,6 +58,10 @@ def _worker(rank, world, port, q, mode):
     else:
         losses = [float(train_step(net, loss_layer, opt, images, target, lr, sync).item()) for lr in LRS]
     torch.cuda.synchronize()
+    if mode == "graphed":
+        # every collective of the graphed path ran in place on a contiguous range of the gradient arena
+        assert sync.in_place_buckets == sync.buckets_issued and sync.buckets_issued > 0, (sync.in_place_buckets, sync.buckets_issued)
+        assert all(p.grad.untyped_storage().data_ptr() == gs.arena.flat.untyped_storage().data_ptr() for p in net.parameters())
     q.put((rank, losses, _pick(net), sync.buckets_issued))
     dist.destroy_process_group()
 

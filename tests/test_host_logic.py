@@ -207,7 +207,7 @@ def _spawn2(target, *extra):
     procs = [ctx.Process(target=target, args=(r, 2, port, q) + extra) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -335,7 +335,7 @@ def _train_seq_worker(rank, world, port, q):
     opt2 = torch.optim.SGD(net2.parameters(), lr=0.05, momentum=0.99)
     gs = GraphedStep.__new__(GraphedStep)
     gs.net, gs.loss_layer, gs.opt, gs.sync = net2, _StubLoss(), opt2, GradSync(None)
-    gs.images, gs.target, gs.two_phase, gs.in_graph_step, gs.phase1, gs.steps_done = x, t, True, False, None, 0
+    gs.images, gs.target, gs.two_phase, gs.in_graph_step, gs.phase1, gs.steps_done, gs.arena = x, t, True, False, None, 0, None
 
     def replay1():
         gs.phase1 = None

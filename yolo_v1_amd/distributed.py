@@ -57,6 +57,8 @@ class GradSync:
         self.pending, self.pending_bytes = [], 0
         self.inflight = []
         self.buckets_issued = 0
+        self.in_place_buckets = 0             # buckets reduced in place inside an ops.GradArena
+        self.arena = None                     # set by train.GraphedStep (data-parallel mode)
         if net is not None:
             net.set_grad_ready_hook(self.on_ready)
 
@@ -82,10 +84,32 @@ class GradSync:
         self._flush()
         self.finish()
 
+    def _arena_range(self):
+        """The pending gradients as ONE contiguous range of the active ops.GradArena, or None (no arena, a gradient that
+        does not live in it, or a range that would cover other parameters' slices)."""
+        from . import ops
+        arena = ops._ARENA[0] if self.arena is None else self.arena
+        if arena is None:
+            return None
+        base = arena.flat.untyped_storage().data_ptr()
+        need = 0
+        for p, g in self.pending:
+            r = arena.ranges.get(id(p))
+            if r is None or g.untyped_storage().data_ptr() != base:
+                return None
+            need += (r[1] + 3) // 4 * 4
+        lo, hi = arena.span([p for p, _ in self.pending])
+        if hi - lo != need:
+            return None
+        return arena.flat[lo:hi]
+
     def _flush(self):
         if not self.pending:
             return
-        flat = torch.cat([_flat_memory_view(g) for _, g in self.pending])
+        flat = self._arena_range()
+        in_place = flat is not None
+        if not in_place:
+            flat = torch.cat([_flat_memory_view(g) for _, g in self.pending])
         work, averaged = None, False
         if dist.is_initialized():
             # RCCL averages in the collective itself (no extra pass over the bucket); gloo only sums
@@ -93,7 +117,8 @@ class GradSync:
             op = dist.ReduceOp.AVG if averaged else dist.ReduceOp.SUM
             work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         self.inflight.append((work, averaged, flat, [p for p, _ in self.pending],
-                              [(g.numel(), tuple(g.shape), tuple(g.stride())) for _, g in self.pending]))
+                              [(g.numel(), tuple(g.shape), tuple(g.stride())) for _, g in self.pending], in_place))
+        self.in_place_buckets += 1 if in_place else 0
         self.pending, self.pending_bytes = [], 0
         self.buckets_issued += 1
 
@@ -101,11 +126,13 @@ class GradSync:
         """Wait for every bucket, average, write the result into ``param.grad``.  Call once per step,
         after ``loss.backward()`` and before ``optimizer.step()``."""
         self._flush()
-        for work, averaged, flat, params, metas in self.inflight:
+        for work, averaged, flat, params, metas, in_place in self.inflight:
             if work is not None:
                 work.wait()
             if self.world > 1 and not averaged:
                 flat.mul_(1.0 / self.world)
+            if in_place:                   # param.grad IS a view of the reduced range (ops.GradArena): nothing to copy
+                continue
             chunks = flat.split([m[0] for m in metas])
             # each chunk holds the gradient in the memory order it was produced in; view it with that
             # layout so the copy is a straight memcpy when param.grad has the same strides

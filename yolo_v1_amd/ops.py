@@ -349,13 +349,67 @@ def _side_stream_for(device):
     return _SIDE_STREAMS[key]
 
 
+class GradArena:
+    """One flat fp32 buffer for every parameter gradient of a backbone.  Slices are handed out in first-use order -- the
+    order the backward executor produces the gradients, which is the order ``distributed.GradSync`` reduces them in --
+    and the same parameter gets the same slice on every later backward.  The weight-gradient / BatchNorm-backward
+    kernels write straight into their slice, ``param.grad`` is a view of it, and a bucket of consecutive parameters is
+    one contiguous range: the all-reduce runs in place, with no flatten pass before it and no copy-back after it
+    (GradSync without an arena concatenates and scatters: two passes over 165 MB per step for ResNet-50)."""
+
+    def __init__(self, net, device):
+        total = sum((p.numel() + 3) // 4 * 4 for p in net.parameters()) + (1 << 18)      # + room for padded output rows
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.ranges = {}                   # id(param) -> (offset, numel)
+        self.top = 0
+
+    def get(self, param, numel):
+        r = self.ranges.get(id(param))
+        if r is None:
+            n4 = (numel + 3) // 4 * 4      # 16-byte aligned slices
+            if self.top + n4 > self.flat.numel():
+                raise _lib.Yv1Error("gradient arena exhausted")
+            r = (self.top, numel)
+            self.ranges[id(param)] = r
+            self.top += n4
+        elif r[1] != numel:
+            raise _lib.Yv1Error("gradient arena: a parameter asked for %d elements, had %d" % (numel, r[1]))
+        return self.flat[r[0]:r[0] + numel]
+
+    def span(self, params):
+        """[lo, hi) of the arena covered by ``params`` (must already have slices); hi is 16-byte rounded."""
+        rs = [self.ranges[id(p)] for p in params]
+        lo = min(r[0] for r in rs)
+        hi = max(r[0] + (r[1] + 3) // 4 * 4 for r in rs)
+        return lo, hi
+
+
+_ARENA = [None]
+
+
+def set_grad_arena(arena):
+    """Activates (or, with None, deactivates) a GradArena for the gradient-producing ops below."""
+    _ARENA[0] = arena
+
+
+def _grad_buf(param, shape):
+    """fp32 tensor of ``shape`` for the gradient of ``param``: its arena slice when an arena is active, else fresh."""
+    n = 1
+    for d in shape:
+        n *= d
+    a = _ARENA[0]
+    if a is not None and param is not None:
+        return a.get(param, n).view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=param.device if param is not None else None)
+
+
 def conv_wgrad(x, dy, w, side=None, after=None):
     """Returns the fp32 gradient as an OIHW view whose storage is [O][kh][kw][I] (channels_last).
     With ``side`` (a SideStream) the kernels run on the side stream, ordered after ``after`` (SideStream.mark())."""
     dev = x.t.device
     L = lib()
     taps = w.k * w.k
-    g = torch.empty((w.Opad, taps, w.Ipad), dtype=torch.float32, device=dev)
+    g = _grad_buf(w.param, (w.Opad, taps, w.Ipad))
     wsb = L.yv1_conv2d_wgrad_workspace_bytes(x.N, dy.H, dy.W, w.Ipad, w.Opad, w.k)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
 
@@ -375,7 +429,7 @@ def stem_wgrad(xp, dy, w, H, W, side=None):
     g = torch.empty((w.O, 7, 32), dtype=torch.float32, device=dev)
     wsb = L.yv1_conv2d_stem_wgrad_workspace_bytes(dy.N, H, W, w.O)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-    out = torch.empty((w.O, 7, 7, 3), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
+    out = _grad_buf(w.param, (w.O, 7, 7, 3)).permute(0, 3, 1, 2)
     so, si, sh, sw = out.stride()
 
     def launch():
@@ -508,20 +562,23 @@ def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=Fals
                                   ptr(st.shift), y.npix, C, mask_mode, ptr(part), s), "yv1_bn_bwd_reduce")
     part, rows = _shrink_partials(part, rows, 2 * C, dev)
     gb = torch.empty((5, C), dtype=torch.float32, device=dev)     # dgamma, dbeta, k1, k2, k3
+    dgam, dbet = gb[0], gb[1]
+    if _ARENA[0] is not None and bn is not None and bn.weight.numel() == C:
+        dgam, dbet = _grad_buf(bn.weight, (C,)), _grad_buf(bn.bias, (C,))
     check(L.yv1_bn_bwd_finalize(ptr(part), rows, C, float(y.npix), ptr(bn.weight) if bn is not None else None,
-                                ptr(st.invstd), ptr(gb[0]), ptr(gb[1]), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), s),
+                                ptr(st.invstd), ptr(dgam), ptr(dbet), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), s),
           "yv1_bn_bwd_finalize")
     if pool_idx is not None:
         check(L.yv1_bn_bwd_apply_pooled(dz.p, dz.ld, ptr(pool_idx), y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale),
                                         ptr(st.shift), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), y.N, y.H, y.W, C, mask_mode,
                                         dy.p, dy.ld, s), "yv1_bn_bwd_apply_pooled")
-        return gb[0], gb[1]
+        return dgam, dbet
     check(L.yv1_bn_bwd_apply(dz.p, dz.ld, zp, zld, y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
                              ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), y.npix, C, mask_mode, dy.p, dy.ld,
                              dres.p if dres is not None else None, dres.ld if dres is not None else 0,
                              1 if accumulate else 0, s),
           "yv1_bn_bwd_apply")
-    return gb[0], gb[1]
+    return dgam, dbet
 
 
 # ------------------------------------------------------------------ pooling / head
@@ -568,8 +625,12 @@ def head_fwd(y, st, C):
 def head_bwd(dout, out, y, st, bn, dy):
     dev = y.t.device
     C = out.shape[-1]
-    gb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    if _ARENA[0] is not None and bn.weight.numel() == C:
+        dgam, dbet = _grad_buf(bn.weight, (C,)), _grad_buf(bn.bias, (C,))
+    else:
+        gb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        dgam, dbet = gb[0], gb[1]
     dout = dout.to(dtype=torch.float32).contiguous()
     check(lib().yv1_head_sigmoid_bwd(ptr(dout), ptr(out), y.p, y.ld, ptr(bn.weight), ptr(st.mean), ptr(st.invstd), dy.p,
-                                     dy.ld, ptr(gb[0]), ptr(gb[1]), y.npix, C, stream_ptr(dev)), "yv1_head_sigmoid_bwd")
-    return gb[0], gb[1]
+                                     dy.ld, ptr(dgam), ptr(dbet), y.npix, C, stream_ptr(dev)), "yv1_head_sigmoid_bwd")
+    return dgam, dbet
