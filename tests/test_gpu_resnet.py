@@ -394,7 +394,10 @@ def test_data_parallel_graphed_step_two_graphs_is_bitwise_the_eager_step():
             for k in ("conv1.weight", "layer1.0.conv1.weight", "layer4.0.downsample.0.weight", "layer5.2.bn3.weight",
                       "bn_end.bias"):
                 assert torch.equal(pa[k], pb[k]), (two_phase, k)
-            assert sync.buckets_issued == 1 + (2 if two_phase else 1) * (len(lrs) - 1)     # eager warm-up + replays
+            assert len(gs.graphs) == (2 if two_phase else 1) and len(gs.phases) == len(gs.graphs) - 1
+            # eager warm-up: one bucket; every replayed step: one collective per phase boundary + one for the rest
+            assert sync.buckets_issued == 1 + len(gs.graphs) * (len(lrs) - 1)
+            assert sync.in_place_buckets == sync.buckets_issued                            # all inside the gradient arena
     finally:
         if created:
             dist.destroy_process_group()

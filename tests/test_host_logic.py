@@ -337,12 +337,14 @@ def _train_seq_worker(rank, world, port, q):
     gs.net, gs.loss_layer, gs.opt, gs.sync = net2, _StubLoss(), opt2, GradSync(None)
     gs.images, gs.target, gs.two_phase, gs.in_graph_step, gs.phase1, gs.steps_done, gs.arena = x, t, True, False, None, 0, None
 
+    gs.phases, gs.graphs = [], []
+
     def replay1():
-        gs.phase1 = None
-        gs.loss = gs._direct(lambda grads: setattr(gs, "phase1", list(grads.items())))
+        gs.phases = []
+        gs.loss = gs._direct(lambda grads: gs.phases.append(list(grads.items())))
     for _ in range(3):
-        gs._dp_sequence(replay1, lambda: None)
-    out["graphed"] = ([p.detach().clone() for p in net2.parameters()], [id(p) for p, _ in gs.phase1] ==
+        gs._dp_sequence([replay1, lambda: None])
+    out["graphed"] = ([p.detach().clone() for p in net2.parameters()], [id(p) for p, _ in gs.phases[0]] ==
                       [id(net2.w3), id(net2.layer4[0])], gs.sync.buckets_issued)
     tonp = lambda ts: [v.numpy().copy() for v in ts]
     out["eager"] = (tonp(out["eager"][0]),) + out["eager"][1:]

@@ -251,7 +251,10 @@ class ResNet(HipBackbone):
         # weight gradients overlap with the dgrad / BN chain on a side stream, unless a gradient-ready hook
         # (overlapped RCCL all-reduce issued from the main stream) needs them in main-stream order
         side = ops.SideStream(dev, enabled=self._grad_ready_hook is None and self.wgrad_side_stream)
-        boundary_blk = self.layer4[0]                 # see HipBackbone.set_phase_boundary
+        # phase boundaries (see HipBackbone.set_phase_boundary): after layer4 -- head + layer5 + layer4 = 79 % of the
+        # gradient bytes after ~10 % of the backward time -- and after layer3 (another 17 %, ~45 % of the time); what
+        # is left for the last, un-overlapped collective is layer2 + layer1 + stem = 1.5 M parameters (6 MB)
+        boundary_blks = [self.layer4[0], self.layer3[0]][:self.phase_boundaries]
         wh = self.cw(self.layer6)
         dyh = ops.new_act(N, yh.H, yh.W, wh.Opad, dev)
         dg, db = ops.head_bwd(gpred, pred, yh, sh, self.bn_end, dyh)
@@ -269,7 +272,7 @@ class ResNet(HipBackbone):
         nblk = len(rec["blocks"])
         for bi, brec in enumerate(reversed(rec["blocks"])):
             g = self.block_backward(brec, g, grads, side if nblk - bi > self.wgrad_main_tail else inline)
-            if self._phase_boundary is not None and brec[0] is boundary_blk:
+            if self._phase_boundary is not None and any(brec[0] is b for b in boundary_blks):
                 side.join()
                 self._phase_boundary(grads)
 

@@ -78,6 +78,7 @@ class HipBackbone(nn.Module):
         self._convw = {}      # ConvParam -> ops.ConvWeights
         self._grad_ready_hook = None
         self._phase_boundary = None
+        self.phase_boundaries = 2          # how many of the executor's phase boundaries call back (train.GraphedStep sets it)
         self.wgrad_side_stream = os.environ.get("YV1_WGRAD_SIDE_STREAM", "1") != "0"
         # weight gradients of the last N residual blocks of the backward (+ the stem) run on the MAIN stream (see
         # OriginResNet._run_backward); measured on ResNet-50 at batch 64
@@ -95,10 +96,11 @@ class HipBackbone(nn.Module):
         self._grad_ready_hook = fn
 
     def set_phase_boundary(self, fn):
-        """``fn(grads_so_far)`` is called ONCE from inside the backward executor, at the point where the deep, parameter-
-        heavy stages are done (ResNet: head, layer5, layer4 = 79 % of the gradient bytes after ~10 % of the backward
-        time) and every kernel launched so far has been joined back onto the main stream.  train.GraphedStep ends its
-        first hipGraph there, so the RCCL all-reduce of those gradients runs beside the replay of the second graph."""
+        """``fn(grads_so_far)`` is called from inside the backward executor at each of its first ``phase_boundaries``
+        phase boundaries: points where a parameter-heavy stage is done (ResNet: after layer4 -- head, layer5, layer4 =
+        79 % of the gradient bytes after ~10 % of the backward time -- and after layer3) and every kernel launched so
+        far has been joined back onto the main stream.  train.GraphedStep ends a hipGraph there, so the RCCL all-reduce
+        of the gradients finished since the previous boundary runs beside the replay of the next graph."""
         self._phase_boundary = fn
 
     def _emit(self, grads, params):

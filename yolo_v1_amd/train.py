@@ -85,12 +85,13 @@ class GraphedStep:
     learning rate in device memory (``FusedSGD``), no host sync inside (``_quiet`` loss layer).
 
     One rank: a single graph holds forward + loss + backward + optimizer.
-    Several ranks: no collective is captured.  The step is TWO graphs split inside the backward pass, where the
-    parameter-heavy deep stages are finished (``HipBackbone.set_phase_boundary``): after replaying the first, the
-    RCCL all-reduce of those gradients (79 % of ResNet-50's bytes) is issued asynchronously and runs on RCCL's
-    stream beside the replay of the second graph (the remaining ~90 % of the backward time); the rest of the
-    gradients follow in one more collective, then the fused optimizer step.  Executors without a phase boundary
-    (DenseNet-121: 38 MB of gradients) use one graph and one collective.
+    Several ranks: no collective is captured.  The step is two (optionally three) graphs split inside the backward pass where
+    parameter-heavy stages are finished (``HipBackbone.set_phase_boundary``: ResNet after layer4 and after layer3):
+    after replaying a graph, the RCCL all-reduce of the gradients it finished (79 %, then 17 % of ResNet-50's bytes)
+    is issued asynchronously and runs on RCCL's stream beside the replay of the next graph; the last 4 % (layer2,
+    layer1, stem: 6 MB) follow in one more collective, then the fused optimizer step.  Gradients live in one flat arena
+    (``ops.GradArena``), so every collective runs in place on a contiguous range.  Executors without a phase
+    boundary (DenseNet-121: 38 MB of gradients) use one graph and one collective.  ``YV1_DP_PHASES`` = 1 / 2 / 3 graphs.
     """
 
     def __init__(self, net, loss_layer, optimizer, images, target, grad_sync=None, warmup=3, two_phase=None,
@@ -106,13 +107,21 @@ class GraphedStep:
         self.images, self.target = images, target
         self.loss_layer.quiet = True
         self.in_graph_step = grad_sync is None
+        # measured with a 1-rank RCCL group: a third graph (boundary after layer3) costs 0.4 ms per step -- the boundary
+        # joins the weight-gradient stream, which lags the main stream by milliseconds that deep into the backward --
+        # about what overlapping another 28 MB of all-reduce is estimated to save on 8 GPUs: two graphs by default
+        nph = int(os.environ.get("YV1_DP_PHASES", "2"))
         if two_phase is None:
-            two_phase = os.environ.get("YV1_DP_PHASES", "2") != "1"
+            two_phase = nph != 1
         self.two_phase = bool(two_phase) and grad_sync is not None and hasattr(net, "layer4")
+        if self.two_phase:
+            net.phase_boundaries = 2 if nph >= 3 else 1
         if grad_sync is not None:
             net.set_grad_ready_hook(None)          # buckets are issued between / after the replays, not from inside a capture
         self.steps_done = 0
-        self.phase1 = None                          # [(param, grad)] finished at the phase boundary
+        self.phase1 = None                          # [(param, grad)] finished at the first phase boundary
+        self.phases = []                            # per boundary: the (param, grad) pairs finished since the previous one
+        self.graphs = []                            # data-parallel mode: the graphs of the step, in replay order
         # data-parallel mode: every parameter gradient lives in one flat arena, in the order the backward produces them;
         # the collectives then run in place on contiguous ranges (no flatten / copy-back passes over 165 MB per step)
         self.arena = None
@@ -185,26 +194,33 @@ class GraphedStep:
 
     def _capture_data_parallel(self, stream):
         import gc
-        self.graph = torch.cuda.CUDAGraph()
-        self.graph2 = torch.cuda.CUDAGraph() if self.two_phase else None
+        self.graphs = [torch.cuda.CUDAGraph()]
+        self.phases = []
         gc.collect()
         torch.cuda.synchronize()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
-            self.graph.capture_begin()
-            state = {"open": self.graph}
+            self.graphs[0].capture_begin()
             try:
+                seen = set()
+
                 def boundary(grads):
-                    self.phase1 = [(p, g) for p, g in grads.items()]
-                    self.graph.capture_end()
-                    self.graph2.capture_begin(pool=self.graph.pool())
-                    state["open"] = self.graph2
+                    # gradients finished since the previous boundary; end this graph, open the next one in the same pool
+                    self.phases.append([(p, g) for p, g in grads.items() if id(p) not in seen])
+                    seen.update(id(p) for p in grads)
+                    self.graphs[-1].capture_end()
+                    nxt = torch.cuda.CUDAGraph()
+                    nxt.capture_begin(pool=self.graphs[0].pool())
+                    self.graphs.append(nxt)
                 self.loss = self._direct(boundary if self.two_phase else None)
             finally:
-                state["open"].capture_end()
+                self.graphs[-1].capture_end()
         torch.cuda.current_stream().wait_stream(stream)
-        if self.two_phase and self.phase1 is None:
+        if self.two_phase and not self.phases:
             raise RuntimeError("the backward executor never reached its phase boundary")
+        self.graph = self.graphs[0]
+        self.graph2 = self.graphs[1] if len(self.graphs) > 1 else None
+        self.phase1 = self.phases[0] if self.phases else None
 
     def _reduce_and_step(self, early):
         """``early``: parameters whose all-reduce is already in flight."""
@@ -212,19 +228,19 @@ class GraphedStep:
         self.sync.reduce_all([(p, p.grad) for p in self.net.parameters() if p.grad is not None and id(p) not in done])
         self.opt.step()
 
-    def _dp_sequence(self, replay1, replay2):
-        """The multi-rank step around the two replays: phase 1 -> asynchronous all-reduce of the gradients finished at
-        the phase boundary (RCCL's stream, beside the second replay) -> phase 2 -> one more collective for the rest ->
-        optimizer.  Kept apart from the graph objects so the CPU gloo test drives this exact sequence."""
+    def _dp_sequence(self, replays):
+        """The multi-rank step around the replays: graph k -> asynchronous all-reduce of the gradients finished at its
+        phase boundary (RCCL's stream, beside the next replay) -> ... -> last graph -> one more collective for the rest
+        -> optimizer.  Kept apart from the graph objects so the CPU gloo test drives this exact sequence."""
         from . import ops
-        replay1()
-        early = None
-        if self.two_phase:
-            early = self.phase1
-            self.sync.start(early)
-            replay2()
+        early = []
+        for k, replay in enumerate(replays):
+            replay()
+            if k < len(self.phases) and k + 1 < len(replays):
+                self.sync.start(self.phases[k])
+                early.extend(self.phases[k])
         ops.bump_weight_epoch()
-        self._reduce_and_step(early)
+        self._reduce_and_step(early or None)
 
     def __call__(self, lr):
         from . import ops
@@ -233,7 +249,7 @@ class GraphedStep:
             self.graph.replay()
             ops.bump_weight_epoch()
             return self.loss
-        self._dp_sequence(self.graph.replay, self.graph2.replay if self.two_phase else None)
+        self._dp_sequence([g.replay for g in self.graphs])
         return self.loss
 
 
