@@ -31,3 +31,18 @@ def load_cases(name):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_memory_between_tests(request):
+    """GPU tests build whole networks, batch-64 activations and hipGraph memory pools; objects caught in reference cycles
+    (captured graphs <-> closures) outlive their test until the collector runs.  Collect and hand the cached blocks back
+    after every GPU test so that a later full-size test does not start on a device that is mostly reserved."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
