@@ -158,6 +158,17 @@ int yv1_bn_bwd_apply(const void* dz, int lddz, const void* z, int ldz, const voi
                      const float* invstd, const float* scale, const float* shift, const float* k1, const float* k2,
                      const float* k3, long long npix, int C, int mask_mode, void* dy, int lddy, void* dres, int lddres,
                      int accumulate, yv1_stream_t stream);
+/* Dual form for a projection Bottleneck (OriginResNet.py:100-105: out = relu(bn3(y3) + bn_d(yd))): bn3 and the
+ * downsample BatchNorm receive the same ReLU-masked gradient; one reduction pass and one apply pass read dz and the
+ * mask once for both.  partials / partials2 have yv1_bn_reduce_rows(npix, C) rows each (finalize them separately). */
+int yv1_bn_bwd_reduce_dual(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                           const float* invstd, const void* y2, int ldy2, const float* mean2, const float* invstd2,
+                           long long npix, int C, int mask_mode, float* partials, float* partials2, yv1_stream_t stream);
+int yv1_bn_bwd_apply_dual(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                          const float* invstd, const float* k1, const float* k2, const float* k3, void* dy, int lddy,
+                          const void* y2, int ldy2, const float* mean2, const float* invstd2, const float* k1b,
+                          const float* k2b, const float* k3b, void* dy2, int lddy2, long long npix, int C, int mask_mode,
+                          yv1_stream_t stream);
 /* BatchNorm(+ReLU) backward behind the stem's 3x3/2 max pool (OriginResNet.py:174-177, OriginDenseNet.py:120-128; autograd
  * of nn.MaxPool2d + nn.ReLU + nn.BatchNorm2d): dpool [N,OH,OW,C] is the gradient of the pool OUTPUT, pool_idx what
  * yv1_maxpool3x3s2_fwd stored; the pool's backward is gathered on the fly, so the 4x larger gradient of the pool input is

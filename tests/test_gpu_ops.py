@@ -458,3 +458,31 @@ def test_conv_fwd_bn_act_inference_epilogue(N, H, Wd, Cin, Cout, k, stride, use_
     ops.conv_fwd_bn_act(nhwc_act(x), wm.cw, ya, ops.bn_eval_state(bn), relu=relu, residual=nhwc_act(res) if use_res else None)
     torch.cuda.synchronize()
     close(to_nchw(ya), ref, rtol=1.5e-2, scale_atol=1.5e-2)
+
+
+@pytest.mark.parametrize("C,N,H", [(256, 4, 12), (512, 3, 7), (2048, 2, 4)])
+def test_bn_backward_dual_is_bitwise_two_single_passes(C, N, H):
+    """The projection-block form (bn3 and the downsample BatchNorm share the masked gradient, OriginResNet.py:100-105):
+    one reduction + one apply pass for both BatchNorms must equal the two separate BatchNorm backwards bit for bit
+    (same per-thread summation order, same coefficients, same arithmetic)."""
+    from yolo_v1_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    ya, yb = nhwc_act(bf(torch.randn(N, C, H, H, generator=g) * 2 + 0.3)), nhwc_act(bf(torch.randn(N, C, H, H, generator=g) - 0.2))
+    bna, bnb = torch.nn.BatchNorm2d(C).to(DEV), torch.nn.BatchNorm2d(C).to(DEV)
+    for bn in (bna, bnb):
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.uniform_(-0.5, 0.5)
+    sta = ops.bn_finalize(ops.bn_stats(ya), ya.npix, bna)
+    stb = ops.bn_finalize(ops.bn_stats(yb), yb.npix, bnb)
+    out = ops.new_act(N, H, H, C, DEV)
+    mask = ops.bn_apply(ya, sta, out, relu=True, residual=yb, res_state=stb, want_mask=True)
+    dz = nhwc_act(bf(torch.randn(N, C, H, H, generator=g)))
+    d1a, d1b = ops.new_act(N, H, H, C, DEV), ops.new_act(N, H, H, C, DEV)
+    ga = ops.bn_backward(dz, ya, sta, bna, d1a, 3, z=mask)
+    gb = ops.bn_backward(dz, yb, stb, bnb, d1b, 3, z=mask)
+    d2a, d2b = ops.new_act(N, H, H, C, DEV), ops.new_act(N, H, H, C, DEV)
+    (ga2, gb2) = ops.bn_backward_dual(dz, mask, (ya, sta, bna, d2a), (yb, stb, bnb, d2b))
+    torch.cuda.synchronize()
+    assert torch.equal(d1a.t, d2a.t) and torch.equal(d1b.t, d2b.t)
+    for x, y in zip(ga + gb, ga2 + gb2):
+        assert torch.equal(x, y)

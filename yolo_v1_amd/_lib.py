@@ -71,6 +71,9 @@ SIGNATURES = {
     "yv1_bn_bwd_finalize": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yv1_bn_bwd_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i,
                                c_p, c_i, c_p, c_i, c_i, c_p]),
+    "yv1_bn_bwd_reduce_dual": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_p]),
+    "yv1_bn_bwd_apply_dual": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p,
+                                    c_p, c_p, c_p, c_i, c_ll, c_i, c_i, c_p]),
     "yv1_bn_bwd_reduce_pooled": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "yv1_bn_bwd_apply_pooled": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
                                       c_p, c_i, c_p]),

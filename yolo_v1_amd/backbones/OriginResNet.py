@@ -209,9 +209,14 @@ class ResNet(HipBackbone):
         if yd is not None:
             wd = self.cw(blk.downsample[0])
             bnd = blk.downsample[1]
-            grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
             dyd = ops.new_act(N, yd.H, yd.W, yd.C, dev)
-            grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
+            # bn3 and the downsample BatchNorm receive the same masked gradient: one reduction + one apply pass for both
+            if self.bn_dual:
+                (grads[blk.bn3.weight], grads[blk.bn3.bias]), (grads[bnd.weight], grads[bnd.bias]) = ops.bn_backward_dual(
+                    g, omask, (y3, s3, blk.bn3, dy3), (yd, sd, bnd, dyd))
+            else:
+                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
+                grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
             grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side)
         else:
             # identity shortcut: its contribution to g_in (g where the block output was positive) is added in

@@ -297,6 +297,13 @@ struct BwdArgs {
   bf16_t* dy; int lddy;
   bf16_t* dres; int lddres;        // optional: masked dz copied out (identity shortcut gradient)
   int accumulate;                  // dy += result (DenseNet: several consumers of one feature map)
+  // dual form (projection Bottleneck, OriginResNet.py:100-105: out = relu(bn3(y3) + bn_d(yd))): a second BatchNorm whose
+  // output gradient is the SAME masked dz -- one pass reads dz and the mask once for both
+  const bf16_t* y2 = nullptr; int ldy2 = 0;
+  const float* mean2 = nullptr; const float* invstd2 = nullptr;
+  float* part2 = nullptr;
+  const float* k1b = nullptr; const float* k2b = nullptr; const float* k3b = nullptr;
+  bf16_t* dy2 = nullptr; int lddy2 = 0;
   // pooled form (stem): dz is the gradient of a 3x3/2 max pool's OUTPUT [N,OH,OW,C]; pool_idx the pool's first-argmax
   // codes; the pixel index p runs over the pool's INPUT [N,pH,pW], whose gradient is gathered on the fly
   const unsigned char* pool_idx = nullptr; int pH = 0, pW = 0;
@@ -395,6 +402,58 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
   block_column_reduce<2, NCOL>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
 }
 
+// Dual form: the masked gradient is shared by two BatchNorms (bn3 and the downsample BatchNorm of a projection block).
+// sum(g) is common; sum(g * xhat) differs -- three running sums per channel, two partial tables (the second table's
+// first row is the same sum(g): the finalize kernel is used unchanged for both).
+template <int NCOL>
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce_dual(BwdArgs a, int TX) {
+  const int CH = a.C >> 3, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  float acc[NCOL][2][8], acc2[NCOL][2][8];
+  float mu[NCOL][8], is[NCOL][8], mu2[NCOL][8], is2[NCOL][8];
+#pragma unroll
+  for (int j = 0; j < NCOL; ++j) {
+    const int col = tx + j * TX;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc[j][0][k] = 0.f; acc[j][1][k] = 0.f; acc2[j][0][k] = 0.f; acc2[j][1][k] = 0.f;
+      mu[j][k] = 0.f; is[j][k] = 0.f; mu2[j][k] = 0.f; is2[j][k] = 0.f;
+    }
+    if (col < CH) {
+      load8f(a.mean + col * 8, mu[j]); load8f(a.invstd + col * 8, is[j]);
+      load8f(a.mean2 + col * 8, mu2[j]); load8f(a.invstd2 + col * 8, is2[j]);
+    }
+  }
+  const long long p0 = (long long)blockIdx.x * a.pix_per_block;
+  const long long p1 = min(a.npix, p0 + a.pix_per_block);
+#pragma unroll 2
+  for (long long p = p0 + ty; p < p1; p += TY) {
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+      const int col = tx + j * TX;
+      if (col < CH) {
+        float yv[8], y2v[8], g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + col * 8), yv);
+        unpack8(*reinterpret_cast<const u32x4*>(a.y2 + p * a.ldy2 + col * 8), y2v);
+        masked_grad(a, p, col * 8, yv, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          acc[j][0][k] += g[k];
+          acc[j][1][k] += g[k] * (yv[k] - mu[j][k]) * is[j][k];
+          acc2[j][1][k] += g[k] * (y2v[k] - mu2[j][k]) * is2[j][k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NCOL; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc2[j][0][k] = acc[j][0][k];
+  block_column_reduce<2, NCOL>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
+  __syncthreads();                                     // block_column_reduce's LDS scratch is reused
+  block_column_reduce<2, NCOL>(acc2, tx, ty, TX, TY, CH, a.C, a.part2 + (size_t)blockIdx.x * 2 * a.C);
+}
+
 // dgamma = sum dyh*xhat, dbeta = sum dyh;  dy = k1*dyh - k2 - xhat*k3 with
 // k1 = gamma*invstd, k2 = k1*dbeta/n, k3 = k1*dgamma/n
 template <int CPB>
@@ -484,6 +543,41 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(BwdArgs a) {
       for (int k = 0; k < 8; ++k) o[k] += old[k];
     }
     *reinterpret_cast<u32x4*>(a.dy + p * a.lddy + c8) = pack8(o);
+  }
+}
+
+// Dual apply: dy = k1*g + ka*y + kb and dy2 = k1b*g + ka2*y2 + kb2 from one read of the gradient and the mask.
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_dual(BwdArgs a) {
+  const int CH = a.C >> 3;
+  // the host rounds the grid so that the grid stride is a multiple of CH: a thread keeps its channel chunk
+  const int c8 = (int)((blockIdx.x * 256u + threadIdx.x) % CH) * 8;
+  float k1[8], ka[8], kb[8], k1b[8], ka2[8], kb2[8];
+  bwd_apply_coeffs(a, c8, k1, ka, kb);
+  {
+    float mu[8], is[8], k2[8], k3[8];
+    load8f(a.mean2 + c8, mu); load8f(a.invstd2 + c8, is);
+    load8f(a.k1b + c8, k1b); load8f(a.k2b + c8, k2); load8f(a.k3b + c8, k3);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float t = is[k] * k3[k];
+      ka2[k] = -t;
+      kb2[k] = mu[k] * t - k2[k];
+    }
+  }
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+  const long long dpix = (long long)gridDim.x * 256 / CH;
+  for (long long p = i0 / (unsigned)CH; p < a.npix; p += dpix) {
+    float yv[8], y2v[8], g[8], o[8], o2[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8), yv);
+    unpack8(*reinterpret_cast<const u32x4*>(a.y2 + p * a.ldy2 + c8), y2v);
+    masked_grad(a, p, c8, yv, g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o[k] = k1[k] * g[k] + (ka[k] * yv[k] + kb[k]);
+      o2[k] = k1b[k] * g[k] + (ka2[k] * y2v[k] + kb2[k]);
+    }
+    *reinterpret_cast<u32x4*>(a.dy + p * a.lddy + c8) = pack8(o);
+    *reinterpret_cast<u32x4*>(a.dy2 + p * a.lddy2 + c8) = pack8(o2);
   }
 }
 
@@ -1212,6 +1306,53 @@ extern "C" int yv1_bn_bwd_apply_pooled(const void* dpool, int lddp, const void* 
   if (!pool_idx || N <= 0 || (mask_mode != 0 && mask_mode != 2)) return YV1_ERR_BAD_ARG;
   return bn_bwd_apply(dpool, lddp, nullptr, 0, y, ldy, mean, invstd, scale, shift, k1, k2, k3, (long long)N * H * W, C, mask_mode,
                       dy, lddy, nullptr, 0, 0, pool_idx, H, W, stream);
+}
+
+// Dual BatchNorm backward (projection Bottleneck: bn3 and the downsample BatchNorm receive the same ReLU-masked
+// gradient, OriginResNet.py:100-105): ONE reduction pass and ONE apply pass read dz and the mask for both.
+// mask_mode 0 / 1 / 3 as yv1_bn_bwd_reduce (2 -- mask from one BatchNorm's own output -- makes no sense for a sum).
+extern "C" int yv1_bn_bwd_reduce_dual(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy,
+                                      const float* mean, const float* invstd, const void* y2, int ldy2, const float* mean2,
+                                      const float* invstd2, long long npix, int C, int mask_mode, float* partials,
+                                      float* partials2, hipStream_t stream) {
+  if (!dz || !y || !y2 || !mean || !invstd || !mean2 || !invstd2 || !partials || !partials2 || npix <= 0) return YV1_ERR_BAD_ARG;
+  if (mask_mode == 2 || ((mask_mode == 1 || mask_mode == 3) && !z)) return YV1_ERR_BAD_ARG;
+  int TX, ppb, blocks; size_t lds;
+  int rc = reduce_geometry(npix, C, &TX, &ppb, &blocks, &lds);
+  if (rc) return rc;
+  if (lddz % 8 || ldy % 8 || ldy2 % 8 || (z && mask_mode == 1 && ldz % 8)) return YV1_ERR_UNSUPPORTED;
+  BwdArgs a = {};
+  a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
+  a.mean = mean; a.invstd = invstd; a.npix = npix; a.C = C; a.pix_per_block = ppb; a.mask_mode = mask_mode; a.part = partials;
+  a.y2 = (const bf16_t*)y2; a.ldy2 = ldy2; a.mean2 = mean2; a.invstd2 = invstd2; a.part2 = partials2;
+  if (C / 8 > TX) hipLaunchKernelGGL(k_bn_bwd_reduce_dual<2>, dim3(blocks), dim3(256), lds, stream, a, TX);
+  else hipLaunchKernelGGL(k_bn_bwd_reduce_dual<1>, dim3(blocks), dim3(256), lds, stream, a, TX);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_bn_bwd_apply_dual(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy,
+                                     const float* mean, const float* invstd, const float* k1, const float* k2,
+                                     const float* k3, void* dy, int lddy, const void* y2, int ldy2, const float* mean2,
+                                     const float* invstd2, const float* k1b, const float* k2b, const float* k3b, void* dy2,
+                                     int lddy2, long long npix, int C, int mask_mode, hipStream_t stream) {
+  if (!dz || !y || !y2 || !mean || !invstd || !mean2 || !invstd2 || !k1 || !k2 || !k3 || !k1b || !k2b || !k3b || !dy || !dy2 ||
+      npix <= 0)
+    return YV1_ERR_BAD_ARG;
+  if (mask_mode == 2 || ((mask_mode == 1 || mask_mode == 3) && !z)) return YV1_ERR_BAD_ARG;
+  if (C % 8 || lddz % 8 || ldy % 8 || ldy2 % 8 || lddy % 8 || lddy2 % 8 || (z && mask_mode == 1 && ldz % 8)) return YV1_ERR_UNSUPPORTED;
+  BwdArgs a = {};
+  a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
+  a.mean = mean; a.invstd = invstd; a.npix = npix; a.C = C; a.mask_mode = mask_mode;
+  a.k1 = k1; a.k2 = k2; a.k3 = k3; a.dy = (bf16_t*)dy; a.lddy = lddy;
+  a.y2 = (const bf16_t*)y2; a.ldy2 = ldy2; a.mean2 = mean2; a.invstd2 = invstd2; a.k1b = k1b; a.k2b = k2b; a.k3b = k3b;
+  a.dy2 = (bf16_t*)dy2; a.lddy2 = lddy2;
+  bool fixed;
+  const int blocks = fixed_chunk_grid(npix * (C / 8), C / 8, &fixed);
+  if (!fixed) return YV1_ERR_UNSUPPORTED;               // every ResNet width qualifies (C/8 a power of two)
+  hipLaunchKernelGGL(k_bn_bwd_apply_dual, dim3(blocks), dim3(256), 0, stream, a);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
 }
 
 // idx (nullable): uint8 [N,OH,OW,C], window position (r*3+s) of the first maximum, consumed by the backward

@@ -581,6 +581,37 @@ def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=Fals
     return dgam, dbet
 
 
+def bn_backward_dual(dz, mask, a, b):
+    """BatchNorm backward of TWO BatchNorms that receive the same ReLU-masked gradient (a projection Bottleneck's bn3 and
+    downsample BatchNorm, OriginResNet.py:100-105): ``a`` / ``b`` = (y, BNState, bn module, dy).  One reduction pass and
+    one apply pass read ``dz`` and the 1-bit ``mask`` once for both.  Returns ((dgamma_a, dbeta_a), (dgamma_b, dbeta_b))."""
+    (ya, sta, bna, dya), (yb, stb, bnb, dyb) = a, b
+    dev = ya.t.device
+    L = lib()
+    C = ya.C
+    s = stream_ptr(dev)
+    rows = L.yv1_bn_reduce_rows(ya.npix, C)
+    pa, pb = _f32(rows * 2 * C, dev), _f32(rows * 2 * C, dev)
+    check(L.yv1_bn_bwd_reduce_dual(dz.p, dz.ld, mask.p, mask.ld, ya.p, ya.ld, ptr(sta.mean), ptr(sta.invstd), yb.p, yb.ld,
+                                   ptr(stb.mean), ptr(stb.invstd), ya.npix, C, 3, ptr(pa), ptr(pb), s), "yv1_bn_bwd_reduce_dual")
+    out, ks = [], []
+    for part, st, bn in ((pa, sta, bna), (pb, stb, bnb)):
+        part, r = _shrink_partials(part, rows, 2 * C, dev)
+        gb = torch.empty((5, C), dtype=torch.float32, device=dev)
+        dgam, dbet = gb[0], gb[1]
+        if _ARENA[0] is not None:
+            dgam, dbet = _grad_buf(bn.weight, (C,)), _grad_buf(bn.bias, (C,))
+        check(L.yv1_bn_bwd_finalize(ptr(part), r, C, float(ya.npix), ptr(bn.weight), ptr(st.invstd), ptr(dgam), ptr(dbet),
+                                    ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), s), "yv1_bn_bwd_finalize")
+        out.append((dgam, dbet))
+        ks.append(gb)
+    check(L.yv1_bn_bwd_apply_dual(dz.p, dz.ld, mask.p, mask.ld, ya.p, ya.ld, ptr(sta.mean), ptr(sta.invstd), ptr(ks[0][2]),
+                                  ptr(ks[0][3]), ptr(ks[0][4]), dya.p, dya.ld, yb.p, yb.ld, ptr(stb.mean), ptr(stb.invstd),
+                                  ptr(ks[1][2]), ptr(ks[1][3]), ptr(ks[1][4]), dyb.p, dyb.ld, ya.npix, C, 3, s),
+          "yv1_bn_bwd_apply_dual")
+    return out[0], out[1]
+
+
 # ------------------------------------------------------------------ pooling / head
 def maxpool_fwd(x, y, want_index=False):
     """3x3/2 max pool; with want_index returns the uint8 first-argmax tensor the backward consumes."""
