@@ -722,8 +722,8 @@ Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int 
     const char* e = getenv("YV1_WGRAD3");            // tuning: 0 disables the multi-tap kernel
     enabled = e ? atoi(e) : 1;
     const char* w = getenv("YV1_WGRAD3_BLOCKS");
-    want_blocks = w ? atoi(w) : 512;
-    if (want_blocks < 32) want_blocks = 512;
+    want_blocks = w ? atoi(w) : 320;                 // in-step sweep: 256-384 beat 512 by ~1 %
+    if (want_blocks < 32) want_blocks = 320;
   }
   // measured (tools/bench_conv.py): 2.0x on 112x112, 1.3x on 56x56, 1.2x on 28x28; 16-pixel segments (14x14 maps) gain
   // nothing over the generic kernel, so rows shorter than 24 pixels stay there
@@ -772,7 +772,7 @@ struct Plan { int bmc, bnc, kp, KT, CT, splitK, steps; };
 
 int wgrad_want_blocks() {
   static int w = 0;
-  if (!w) { const char* e = getenv("YV1_WGRAD_BLOCKS"); w = e ? atoi(e) : 768; if (w < 64) w = 768; }
+  if (!w) { const char* e = getenv("YV1_WGRAD_BLOCKS"); w = e ? atoi(e) : 512; if (w < 64) w = 512; }
   return w;
 }
 
@@ -799,7 +799,8 @@ Plan make_plan(int M, int Cin, int Cout, int taps) {
   if (p.kp == 128 && p.bmc == 128 && p.bnc == 128) p.kp = 64;      // LDS budget
   const int tiles = p.KT * p.CT * taps;
   const int total_steps = (M + p.kp - 1) / p.kp;
-  int want = (wgrad_want_blocks() + tiles - 1) / tiles;   // aim for 2-3 workgroups per CU
+  int want = (wgrad_want_blocks() + tiles - 1) / tiles;   // 2 workgroups per CU: the side stream shares the device with the
+                                                          // main stream, and every split costs a slab written and read back
   int maxsplit = total_steps / (512 / p.kp);        // at least 512 pixels per split
   if (maxsplit < 1) maxsplit = 1;
   if (want > maxsplit) want = maxsplit;
