@@ -124,6 +124,12 @@ size_t yv1_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout
 int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx, int Cin, int Cout,
                                int lddy, int k, int stride, int pad, void* workspace, size_t workspace_bytes,
                                yv1_stream_t stream);
+/* The same for a launch that overlaps with another stream's kernels (the backward runs the weight gradients on a side
+ * stream beside the dgrad / BatchNorm chain): narrower split-K -- fewer slabs, fewer workgroups taken from the other
+ * stream.  Same workspace size query; the result differs from the entry above in fp32 summation order only. */
+int yv1_conv2d_wgrad_shared_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx, int Cin,
+                                      int Cout, int lddy, int k, int stride, int pad, void* workspace,
+                                      size_t workspace_bytes, yv1_stream_t stream);
 size_t yv1_conv2d_stem_wgrad_workspace_bytes(int N, int H, int W, int Cout);
 int yv1_conv2d_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int N, int H, int W, int Cout, int lddy,
                                void* workspace, size_t workspace_bytes, yv1_stream_t stream);

@@ -57,6 +57,8 @@ SIGNATURES = {
     # wgrad.hip
     "yv1_conv2d_wgrad_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "yv1_conv2d_wgrad_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "yv1_conv2d_wgrad_shared_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_sz,
+                                                c_p]),
     "yv1_conv2d_stem_wgrad_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "yv1_conv2d_stem_wgrad_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     # elementwise.hip

@@ -217,17 +217,22 @@ class ResNet(HipBackbone):
             else:
                 grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
                 grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
-            grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side)
         else:
             # identity shortcut: its contribution to g_in (g where the block output was positive) is added in
             # the epilogue of conv1's dgrad below
             grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
         # the data gradient (critical path) is enqueued BEFORE the weight gradient that reads the same dy: launched
         # the other way round, the side stream's wgrad workgroups fill the CUs first and the dgrad waits behind
-        # them (50 us per layer in the trace); this way the wgrad runs beside the bandwidth-bound BN kernels
+        # them (50 us per layer in the trace); this way the wgrad runs beside the bandwidth-bound BN kernels.
+        # Inside a captured hipGraph the order decides more: the HIP runtime hands a node's FIRST captured successor the
+        # node's own queue and every further successor another one, so a weight gradient captured before the next
+        # main-chain kernel pushes the main chain onto a new queue -- after four such forks (the projection blocks) it
+        # wrapped around onto the weight gradients' queue and layer2's backward ran serialized with them
         mk = side.mark()
         dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
         ops.conv_dgrad(dy3, w3, dz2)
+        if yd is not None:
+            grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side, after=mk)
         grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side, after=mk)
         dy2 = ops.new_act(N, y2.H, y2.W, y2.C, dev)
         grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
@@ -264,9 +269,10 @@ class ResNet(HipBackbone):
         dyh = ops.new_act(N, yh.H, yh.W, wh.Opad, dev)
         dg, db = ops.head_bwd(gpred, pred, yh, sh, self.bn_end, dyh)
         grads[self.bn_end.weight], grads[self.bn_end.bias] = dg, db
-        grads[self.layer6.weight] = ops.conv_wgrad(x, dyh, wh, side)
+        mk = side.mark()
         g = ops.new_act(N, x.H, x.W, x.C, dev)
-        ops.conv_dgrad(dyh, wh, g)
+        ops.conv_dgrad(dyh, wh, g)                  # main chain first: it keeps the capture's queue (see block_backward)
+        grads[self.layer6.weight] = ops.conv_wgrad(x, dyh, wh, side, after=mk)
         self._emit(grads, [self.bn_end.weight, self.bn_end.bias, self.layer6.weight])
 
         # The side stream gets little of the chip while the main stream's kernels run and finishes its queue alone after

@@ -1055,8 +1055,17 @@ int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 // grid for the elementwise BatchNorm kernels: rounded down to a multiple of CH / gcd(CH, 256) so that the grid stride
 // keeps every thread on one channel chunk (any C: DenseNet's 96, 160, ... too); *fixed says whether that holds
 int ew_blocks(long long total);
+// The streaming BatchNorm apply / backward-apply kernels (16 bytes per lane and tensor, a handful of FMAs) reach the HBM rate
+// with four 256-thread workgroups per CU looping over the tensor; launching one workgroup per 256 chunks (16384 of them)
+// was 6-17 % slower on the same tensors (tools/bench_bn.py: 1024@28 backward-apply 93 -> 78 us, 256@112 apply 237 -> 222 us)
+// and 2.4 % in the ResNet-50 step -- the dispatcher hands out 60 rounds of short workgroups instead of one resident set.
+int bn_stream_blocks(long long total) {
+  static long long cap = [] { const char* e = getenv("YV1_BN_EW_BLOCKS"); long long v = e ? atoll(e) : 1024; return v < 64 ? 1024 : v; }();
+  long long b = (total + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
 int fixed_chunk_grid(long long total, int CH, bool* fixed) {
-  int blocks = ew_blocks(total);
+  int blocks = bn_stream_blocks(total);
   int g = CH, b = 256;
   while (b) { const int t = g % b; g = b; b = t; }      // gcd(CH, 256)
   const int m = CH / g;

@@ -715,16 +715,24 @@ __global__ void __launch_bounds__(256, 2) k_wgrad3x3(W3Args a) {
 
 struct Plan3 { bool use; int kp, spr, total_steps, steps, splitK, KT, CT, bmc; };
 
-Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+// shared: the launch overlaps with another stream's kernels (the backward's side stream) -- a narrower split-K then wins:
+// fewer slabs to write and re-read, fewer workgroups taken from the other stream (in-step sweep, DESIGN.md section 7:
+// 512/320 target workgroups beat 768/512 by 1.3 %); a launch that has the device to itself wants the wider split
+// (serialized backward: 768/512 beat 512/320 by 2.9 % and 1024/768 by 5 %).
+Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad, bool shared) {
   Plan3 p;
-  static int enabled = -1, want_blocks = 0;
+  static int enabled = -1, want_shared = 0, want_alone = 0;
   if (enabled < 0) {
     const char* e = getenv("YV1_WGRAD3");            // tuning: 0 disables the multi-tap kernel
     enabled = e ? atoi(e) : 1;
     const char* w = getenv("YV1_WGRAD3_BLOCKS");
-    want_blocks = w ? atoi(w) : 320;                 // in-step sweep: 256-384 beat 512 by ~1 %
-    if (want_blocks < 32) want_blocks = 320;
+    want_shared = w ? atoi(w) : 320;
+    if (want_shared < 32) want_shared = 320;
+    const char* wa = getenv("YV1_WGRAD3_BLOCKS_ALONE");
+    want_alone = wa ? atoi(wa) : 512;
+    if (want_alone < 32) want_alone = 512;
   }
+  const int want_blocks = shared ? want_shared : want_alone;
   // measured (tools/bench_conv.py): 2.0x on 112x112, 1.3x on 56x56, 1.2x on 28x28; 16-pixel segments (14x14 maps) gain
   // nothing over the generic kernel, so rows shorter than 24 pixels stay there
   const bool square = Cin % 64 == 0 && Cout % 64 == 0 && W >= 24;
@@ -770,10 +778,13 @@ int launch(WgradArgs& a, int nblocks, hipStream_t stream) {
 
 struct Plan { int bmc, bnc, kp, KT, CT, splitK, steps; };
 
-int wgrad_want_blocks() {
-  static int w = 0;
-  if (!w) { const char* e = getenv("YV1_WGRAD_BLOCKS"); w = e ? atoi(e) : 512; if (w < 64) w = 512; }
-  return w;
+int wgrad_want_blocks(bool shared) {
+  static int w = 0, wa = 0;
+  if (!w) {
+    const char* e = getenv("YV1_WGRAD_BLOCKS"); w = e ? atoi(e) : 512; if (w < 64) w = 512;
+    const char* a = getenv("YV1_WGRAD_BLOCKS_ALONE"); wa = a ? atoi(a) : 768; if (wa < 64) wa = 768;
+  }
+  return shared ? w : wa;
 }
 
 int wgrad_kp() {
@@ -782,7 +793,7 @@ int wgrad_kp() {
   return kp;
 }
 
-Plan make_plan(int M, int Cin, int Cout, int taps) {
+Plan make_plan(int M, int Cin, int Cout, int taps, bool shared) {
   Plan p;
   // DenseNet's 1x1 bottlenecks (Cout 128, Cin = 64 + 32 i): a partial last 128-wide Cin tile (masked loads) beats
   // 32- or 64-wide tiles that re-read dY once per tile, as long as at most a quarter of the tile columns are padding
@@ -799,8 +810,7 @@ Plan make_plan(int M, int Cin, int Cout, int taps) {
   if (p.kp == 128 && p.bmc == 128 && p.bnc == 128) p.kp = 64;      // LDS budget
   const int tiles = p.KT * p.CT * taps;
   const int total_steps = (M + p.kp - 1) / p.kp;
-  int want = (wgrad_want_blocks() + tiles - 1) / tiles;   // 2 workgroups per CU: the side stream shares the device with the
-                                                          // main stream, and every split costs a slab written and read back
+  int want = (wgrad_want_blocks(shared) + tiles - 1) / tiles;   // 2-3 workgroups per CU; every split costs a slab written and read back
   int maxsplit = total_steps / (512 / p.kp);        // at least 512 pixels per split
   if (maxsplit < 1) maxsplit = 1;
   if (want > maxsplit) want = maxsplit;
@@ -860,19 +870,25 @@ extern "C" size_t yv1_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Ci
   // plans for 3x3 shapes (the stride-1 plan is the larger one whenever it applies)
   size_t need3 = 0;
   if (k == 3) {
-    const Plan3 p3 = make_plan3(N, OH, OW, Cin, Cout, 3, 1, 1);
-    if (p3.use) need3 = (size_t)p3.splitK * Cout * 9 * Cin * sizeof(float);
+    for (int shared = 0; shared < 2; ++shared) {
+      const Plan3 p3 = make_plan3(N, OH, OW, Cin, Cout, 3, 1, 1, shared != 0);
+      const size_t n3 = p3.use ? (size_t)p3.splitK * Cout * 9 * Cin * sizeof(float) : 0;
+      if (n3 > need3) need3 = n3;
+    }
   }
-  const Plan p = make_plan(N * OH * OW, Cin, Cout, k * k);
-  const size_t need = p.splitK > 1 ? (size_t)p.splitK * Cout * k * k * Cin * sizeof(float) : 0;
+  size_t need = 0;
+  for (int shared = 0; shared < 2; ++shared) {             // one size serves both entry points
+    const Plan p = make_plan(N * OH * OW, Cin, Cout, k * k, shared != 0);
+    const size_t n = p.splitK > 1 ? (size_t)p.splitK * Cout * k * k * Cin * sizeof(float) : 0;
+    if (n > need) need = n;
+  }
   return need > need3 ? need : need3;
 }
 
 // dw[Cout][k*k][Cin] fp32 = sum over pixels of dy (x) x_tap.   x: [N,IH,IW,*] (pixel stride ldx),
 // dy: [N,OH,OW,*] (pixel stride lddy).  workspace: yv1_conv2d_wgrad_workspace_bytes().
-extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx,
-                                          int Cin, int Cout, int lddy, int k, int stride, int pad, void* workspace,
-                                          size_t workspace_bytes, hipStream_t stream) {
+static int conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx, int Cin, int Cout, int lddy,
+                        int k, int stride, int pad, void* workspace, size_t workspace_bytes, bool shared, hipStream_t stream) {
   yv1_cfg_reset();
   if (!x || !dy || !dw || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
   if (Cin % 32 || ldx % 8 || lddy % 8 || Cout % 8) return YV1_ERR_UNSUPPORTED;
@@ -883,7 +899,7 @@ extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
   a.Cin = Cin; a.Cout = Cout; a.R = k; a.S = k;
   a.ah = stride; a.bh = 1; a.ch = -pad; a.aw = stride; a.bw = 1; a.cw = -pad;
   a.M = N * a.P * a.Q;
-  const Plan3 p3 = make_plan3(N, IH, IW, Cin, Cout, k, stride, pad);
+  const Plan3 p3 = make_plan3(N, IH, IW, Cin, Cout, k, stride, pad, shared);
   if (p3.use) {
     const size_t need3 = (size_t)p3.splitK * Cout * 9 * Cin * sizeof(float);
     if (need3 > workspace_bytes || !workspace) return YV1_ERR_WORKSPACE;
@@ -901,7 +917,7 @@ extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     YV1_LAUNCH_CHECK();
     return YV1_OK;
   }
-  const Plan p = make_plan(a.M, Cin, Cout, k * k);
+  const Plan p = make_plan(a.M, Cin, Cout, k * k, shared);
   const size_t need = p.splitK > 1 ? (size_t)p.splitK * Cout * k * k * Cin * sizeof(float) : 0;
   if (need > workspace_bytes || (need && !workspace)) return YV1_ERR_WORKSPACE;
   a.splitK = p.splitK; a.steps_per_split = p.steps; a.CT = p.CT; a.KT = p.KT;
@@ -917,6 +933,20 @@ extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     YV1_LAUNCH_CHECK();
   }
   return YV1_OK;
+}
+
+extern "C" int yv1_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx,
+                                          int Cin, int Cout, int lddy, int k, int stride, int pad, void* workspace,
+                                          size_t workspace_bytes, hipStream_t stream) {
+  return conv2d_wgrad(x, dy, dw, N, IH, IW, ldx, Cin, Cout, lddy, k, stride, pad, workspace, workspace_bytes, false, stream);
+}
+
+// The same gradient (bitwise different: another split-K width, i.e. another summation order) for a launch that overlaps with
+// kernels of another stream -- the backward's weight-gradient stream beside the dgrad / BatchNorm chain: narrower split-K.
+extern "C" int yv1_conv2d_wgrad_shared_nhwc_bf16(const void* x, const void* dy, float* dw, int N, int IH, int IW, int ldx,
+                                                 int Cin, int Cout, int lddy, int k, int stride, int pad, void* workspace,
+                                                 size_t workspace_bytes, hipStream_t stream) {
+  return conv2d_wgrad(x, dy, dw, N, IH, IW, ldx, Cin, Cout, lddy, k, stride, pad, workspace, workspace_bytes, true, stream);
 }
 
 // Stem weight gradient: x is the packed NHWC4 image [N][H+6][W+6][4]; dw comes out as [Cout][7][32]

@@ -82,7 +82,7 @@ class HipBackbone(nn.Module):
         self.wgrad_side_stream = os.environ.get("YV1_WGRAD_SIDE_STREAM", "1") != "0"
         # weight gradients of the last N residual blocks of the backward (+ the stem) run on the MAIN stream (see
         # OriginResNet._run_backward); measured on ResNet-50 at batch 64
-        self.wgrad_main_tail = int(os.environ.get("YV1_WGRAD_MAIN_TAIL", "2"))
+        self.wgrad_main_tail = int(os.environ.get("YV1_WGRAD_MAIN_TAIL", "0"))
         self.bn_dual = os.environ.get("YV1_BN_DUAL", "1") != "0"         # projection blocks: bn3 + downsample BN backward in one pass
         self.fused_eval = os.environ.get("YV1_FUSED_EVAL", "1") != "0"   # eval(): BatchNorm folded into the conv epilogue
         # training: run the forward convolutions on the fp8 (e4m3) MFMA path -- "fp8 forward GEMMs, bf16 backward"

@@ -413,9 +413,13 @@ def conv_wgrad(x, dy, w, side=None, after=None):
     wsb = L.yv1_conv2d_wgrad_workspace_bytes(x.N, dy.H, dy.W, w.Ipad, w.Opad, w.k)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
 
+    # beside the main stream's kernels a narrower split-K wins, alone on the device the wider one (see yv1.h)
+    overlapped = side is not None and side.side is not None
+    fn = L.yv1_conv2d_wgrad_shared_nhwc_bf16 if overlapped else L.yv1_conv2d_wgrad_nhwc_bf16
+
     def launch():
-        check(L.yv1_conv2d_wgrad_nhwc_bf16(x.p, dy.p, ptr(g), x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, dy.ld, w.k, w.stride,
-                                           w.pad, ptr(ws), wsb, stream_ptr(dev)), "yv1_conv2d_wgrad_nhwc_bf16")
+        check(fn(x.p, dy.p, ptr(g), x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, dy.ld, w.k, w.stride, w.pad, ptr(ws), wsb,
+                 stream_ptr(dev)), "yv1_conv2d_wgrad_nhwc_bf16")
     if side is None:
         launch()
     else:
