@@ -460,6 +460,38 @@ def test_conv_fwd_bn_act_inference_epilogue(N, H, Wd, Cin, Cout, k, stride, use_
     close(to_nchw(ya), ref, rtol=1.5e-2, scale_atol=1.5e-2)
 
 
+def test_side_stream_refuses_side_work_captured_before_the_next_main_kernel():
+    """hipGraph queue assignment: the first captured successor of a node keeps the node's hardware
+    queue.  SideStream.run(after=mark) inside a capture therefore insists that a main-stream launch followed the mark --
+    a weight gradient captured first would move the main chain to another queue.  Eager launches are not restricted."""
+    from yolo_v1_amd import ops, _lib
+    g = torch.Generator().manual_seed(5)
+    w = W(bf(torch.randn(64, 64, 1, 1, generator=g) * 0.1), 1, 1, 0)
+    xa = nhwc_act(bf(torch.randn(2, 64, 8, 8, generator=g)))
+    dya = nhwc_act(bf(torch.randn(2, 64, 8, 8, generator=g)))
+    dxa = ops.new_act(2, 8, 8, 64, DEV)
+    dev = torch.device(DEV)
+    side = ops.SideStream(dev, enabled=True)            # eager: any order is accepted
+    mk = side.mark()
+    ops.conv_wgrad(xa, dya, w.cw, side, after=mk)
+    side.join()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream(DEV)
+    with torch.cuda.stream(s):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            side = ops.SideStream(dev, enabled=True)
+            ops.conv_dgrad(dya, w.cw, dxa)
+            mk = side.mark()
+            with pytest.raises(_lib.Yv1Error, match="main-stream launch"):
+                ops.conv_wgrad(xa, dya, w.cw, side, after=mk)
+            ops.conv_dgrad(dya, w.cw, dxa)               # the main chain's next kernel first ...
+            ops.conv_wgrad(xa, dya, w.cw, side, after=mk)   # ... then the side work: accepted
+            side.join()
+        graph.replay()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("C,N,H", [(256, 4, 12), (512, 3, 7), (2048, 2, 4)])
 def test_bn_backward_dual_is_bitwise_two_single_passes(C, N, H):
     """The projection-block form (bn3 and the downsample BatchNorm share the masked gradient, OriginResNet.py:100-105):

@@ -136,7 +136,11 @@ def ptr(t):
     return c_p(t.data_ptr()) if t is not None else c_p(0)
 
 
+LAUNCHES = [0]          # C-ABI calls made so far (every kernel launch goes through check()); ops.SideStream reads it
+
+
 def check(code, what):
+    LAUNCHES[0] += 1
     if code != 0:
         names = {1001: "bad argument", 1002: "unsupported shape", 1003: "workspace too small"}
         raise Yv1Error("%s failed: code %d (%s)" % (what, code, names.get(code, "hipError_t")))

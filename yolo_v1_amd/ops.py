@@ -315,6 +315,7 @@ class SideStream:
             return None
         ev = torch.cuda.Event()
         ev.record(self.main)
+        self._mark_launches = (ev, _lib.LAUNCHES[0])
         return ev
 
     def run(self, fn, *keep_alive, after=None):
@@ -323,6 +324,14 @@ class SideStream:
         if self.side is None:
             return fn()
         if after is not None:
+            # Inside a capture the HIP graph executor gives a node's FIRST captured successor the node's own hardware queue
+            # and pushes later successors to other queues: side work captured before the next main-chain kernel moves the
+            # main chain off its queue (after four such forks it shared a queue with the weight gradients: -3 % at S=7,
+            # -10 % at S=14).  A mark must therefore be followed by a main-stream launch first.
+            m = getattr(self, "_mark_launches", None)
+            if m is not None and m[0] is after and m[1] == _lib.LAUNCHES[0] and torch.cuda.is_current_stream_capturing():
+                raise _lib.Yv1Error("SideStream.run(after=mark) captured before any main-stream launch since mark(): "
+                                    "enqueue the main chain's next kernel first (hipGraph queue assignment)")
             self.side.wait_event(after)
         else:
             self.side.wait_stream(self.main)
