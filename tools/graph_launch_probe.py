@@ -42,3 +42,12 @@ for _ in range(10):
     gs(1e-3)
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("10 back-to-back replays: host %.2f ms per call, %.2f ms per step" % ((t1 - t0) * 100, (t2 - t0) * 100))
+# the learning rate changes every iteration (train.py:22-32 warm-up): an eager fill of the device-side lr between replays
+for name, lrs in (("constant lr", [1e-3] * 30), ("lr changing every step", [1e-3 + 1e-6 * i for i in range(30)])):
+    for lr in lrs[:5]:
+        gs(lr)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for lr in lrs[5:]:
+        gs(lr)
+    torch.cuda.synchronize()
+    print("%-24s %.3f ms per step" % (name, (time.perf_counter() - t0) * 1e3 / 25))
