@@ -615,7 +615,7 @@ __device__ __forceinline__ void pooled_patch_grad(const BwdArgs& a, unsigned n, 
 }
 
 // reduce over patches: a.npix = number of patches, a.pix_per_block patches per block; C <= 8*TX (one column per thread)
-__global__ void __launch_bounds__(256) k_bn_bwd_reduce_pool2(BwdArgs a, int TX) {
+__global__ void __launch_bounds__(256, 3) k_bn_bwd_reduce_pool2(BwdArgs a, int TX) {
   const int CH = a.C >> 3, TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int OH = a.pH >> 1, OW = a.pW >> 1;
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_pool2(BwdArgs a, int TX) 
   block_column_reduce<2, 1>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
 }
 
-__global__ void __launch_bounds__(256) k_bn_bwd_apply_pool2(BwdArgs a) {
+__global__ void __launch_bounds__(256, 4) k_bn_bwd_apply_pool2(BwdArgs a) {
   const int CH = a.C >> 3, OH = a.pH >> 1, OW = a.pW >> 1;
   const long long total = a.npix * CH;                    // a.npix = number of patches
   // the grid stride is a multiple of CH when CH divides 256 (the stems: CH = 8): a thread then keeps its channel chunk
