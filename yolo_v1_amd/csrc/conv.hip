@@ -165,6 +165,41 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
   // ---- epilogue 3: full-line stores, 16 B (8 channels) per lane
   constexpr int OCPR = BN / 8;
   constexpr int OPASSES = (BM * OCPR + NTH - 1) / NTH;
+  // shortcut-gradient operands of ALL passes up front: inside the loop every load sits behind the previous pass's store
+  // (the compiler cannot prove Y and AS apart), i.e. one memory round trip per pass instead of one per tile
+  uint4 as_pre[OPASSES];
+  unsigned am_pre[OPASSES];
+  if (a.AS) {
+#pragma unroll
+    for (int i = 0; i < OPASSES; ++i) {
+      const int idx = tid + i * NTH;
+      const int row = idx / OCPR, cc = idx - row * OCPR;
+      const int m = m0 + row;
+      if (row < BM && m < a.M) {
+        as_pre[i] = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + n0 + cc * 8);
+        am_pre[i] = a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)];
+      }
+    }
+  } else if (a.accumulate) {                 // the destination's old values, likewise (AS and accumulate are never combined)
+#pragma unroll
+    for (int i = 0; i < OPASSES; ++i) {
+      const int idx = tid + i * NTH;
+      const int row = idx / OCPR, cc = idx - row * OCPR;
+      const int m = m0 + row;
+      if (row < BM && m < a.M) {
+        size_t off;
+        if (a.os == 1) {
+          off = (size_t)m * a.ldy + n0 + cc * 8;
+        } else {
+          const int pq = a.P * a.Q;
+          const int n = m / pq, rem = m - n * pq;
+          const int p = rem / a.Q, q = rem - p * a.Q;
+          off = ((size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0) * a.ldy + n0 + cc * 8;
+        }
+        as_pre[i] = *reinterpret_cast<const uint4*>(a.Y + off);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < OPASSES; ++i) {
     const int idx = tid + i * NTH;
@@ -182,8 +217,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
       }
       uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
       if (a.AS) {
-        const uint4 o = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + n0 + cc * 8);
-        const unsigned mb = a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)];
+        const uint4 o = as_pre[i];
+        const unsigned mb = am_pre[i];
         const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
         const unsigned* po = reinterpret_cast<const unsigned*>(&o);
         unsigned res[4];
@@ -211,7 +246,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         v = make_uint4(res[0], res[1], res[2], res[3]);
       }
       if (a.accumulate) {
-        const uint4 o = *reinterpret_cast<const uint4*>(a.Y + off);
+        const uint4 o = a.AS ? *reinterpret_cast<const uint4*>(a.Y + off) : as_pre[i];
         const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
         const unsigned* po = reinterpret_cast<const unsigned*>(&o);
         unsigned res[4];
@@ -1355,9 +1390,12 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
   }
   ConvPlan p = plan_conv(a.M, a.Cout, a.Cin, a.R * a.S);
   // The shortcut-adding dgrad (yv1_conv2d_dgrad_add_masked_nhwc_bf16) streams three 4p-wide tensors per tile through a
-  // generic epilogue whose loads the prefetch cannot hide: on the 112x112 / 56x56 maps one tile per workgroup is 7-10 %
-  // faster than persistent workgroups (232 vs 249 us, 132 vs 148 us; equal from 28x28 down)
-  if (p.kind == 2 && a.AS && a.M >= 150000) p.kind = 1;
+  // generic epilogue.  One tile per workgroup, whose epilogue fetches the shortcut operands of all its store passes up front,
+  // beats the persistent form (which waits once per 16-row group): 198 vs 249 us at 112x112, 122 vs 148 us at 56x56,
+  // 68 vs 72 us at 28x28, level below
+  static int as_min_m = -1;
+  if (as_min_m < 0) as_min_m = env_int("YV1_AS_DMA_MIN_M", 0);
+  if (p.kind == 2 && a.AS && a.M >= as_min_m) p.kind = 1;
   if (p.kind == 0) {
     const bool k64 = p.bk == 64;
     if (p.bm == 128 && p.bn == 128) return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
