@@ -402,10 +402,74 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(BwdArgs a, int TX) {
   block_column_reduce<2, NCOL>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
 }
 
+// The same reduction with the mask mode as a template parameter (no pooled gather): the loads of an iteration -- y, dz and
+// the mask source -- are issued together instead of one per run-time branch with a wait after each.  Same summation order.
+template <int NCOL, int MODE>
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce_s(BwdArgs a, int TX) {
+  const int CH = a.C >> 3, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  float acc[NCOL][2][8];
+  float mu[NCOL][8], is[NCOL][8], sc[NCOL][8], sh[NCOL][8];
+#pragma unroll
+  for (int j = 0; j < NCOL; ++j) {
+    const int col = tx + j * TX;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { acc[j][0][k] = 0.f; acc[j][1][k] = 0.f; mu[j][k] = 0.f; is[j][k] = 0.f; sc[j][k] = 0.f; sh[j][k] = 0.f; }
+    if (col < CH) {
+      load8f(a.mean + col * 8, mu[j]); load8f(a.invstd + col * 8, is[j]);
+      if (MODE == 2) { load8f(a.scale + col * 8, sc[j]); load8f(a.shift + col * 8, sh[j]); }
+    }
+  }
+  const long long p0 = (long long)blockIdx.x * a.pix_per_block;
+  const long long p1 = min(a.npix, p0 + a.pix_per_block);
+#pragma unroll 2
+  for (long long p = p0 + ty; p < p1; p += TY) {
+    u32x4 yq[NCOL], gq[NCOL], zq[NCOL];
+    unsigned mq[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+      const int col = tx + j * TX;
+      if (col < CH) {
+        yq[j] = *reinterpret_cast<const u32x4*>(a.y + p * a.ldy + col * 8);
+        gq[j] = *reinterpret_cast<const u32x4*>(a.dz + p * a.lddz + col * 8);
+        if (MODE == 1) zq[j] = *reinterpret_cast<const u32x4*>(a.z + p * a.ldz + col * 8);
+        if (MODE == 3) mq[j] = reinterpret_cast<const unsigned char*>(a.z)[p * a.ldz + col];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+      const int col = tx + j * TX;
+      if (col < CH) {
+        float yv[8], g[8];
+        unpack8(yq[j], yv);
+        unpack8(gq[j], g);
+        if (MODE == 1) {
+          float zv[8];
+          unpack8(zq[j], zv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = zv[k] > 0.f ? g[k] : 0.f;
+        } else if (MODE == 3) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = ((mq[j] >> k) & 1u) ? g[k] : 0.f;
+        } else if (MODE == 2) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = (yv[k] * sc[j][k] + sh[j][k]) > 0.f ? g[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          acc[j][0][k] += g[k];
+          acc[j][1][k] += g[k] * (yv[k] - mu[j][k]) * is[j][k];
+        }
+      }
+    }
+  }
+  block_column_reduce<2, NCOL>(acc, tx, ty, TX, TY, CH, a.C, a.part + (size_t)blockIdx.x * 2 * a.C);
+}
+
 // Dual form: the masked gradient is shared by two BatchNorms (bn3 and the downsample BatchNorm of a projection block).
 // sum(g) is common; sum(g * xhat) differs -- three running sums per channel, two partial tables (the second table's
 // first row is the same sum(g): the finalize kernel is used unchanged for both).
-template <int NCOL>
+template <int NCOL, int MODE>
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce_dual(BwdArgs a, int TX) {
   const int CH = a.C >> 3, TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -432,10 +496,27 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_dual(BwdArgs a, int TX) {
     for (int j = 0; j < NCOL; ++j) {
       const int col = tx + j * TX;
       if (col < CH) {
+        // every load of the iteration first (mask mode at compile time: see k_bn_bwd_reduce_s)
+        const u32x4 yq = *reinterpret_cast<const u32x4*>(a.y + p * a.ldy + col * 8);
+        const u32x4 y2q = *reinterpret_cast<const u32x4*>(a.y2 + p * a.ldy2 + col * 8);
+        const u32x4 gq = *reinterpret_cast<const u32x4*>(a.dz + p * a.lddz + col * 8);
+        u32x4 zq;
+        unsigned mq = 0;
+        if (MODE == 1) zq = *reinterpret_cast<const u32x4*>(a.z + p * a.ldz + col * 8);
+        if (MODE == 3) mq = reinterpret_cast<const unsigned char*>(a.z)[p * a.ldz + col];
         float yv[8], y2v[8], g[8];
-        unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + col * 8), yv);
-        unpack8(*reinterpret_cast<const u32x4*>(a.y2 + p * a.ldy2 + col * 8), y2v);
-        masked_grad(a, p, col * 8, yv, g);
+        unpack8(yq, yv);
+        unpack8(y2q, y2v);
+        unpack8(gq, g);
+        if (MODE == 1) {
+          float zv[8];
+          unpack8(zq, zv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = zv[k] > 0.f ? g[k] : 0.f;
+        } else if (MODE == 3) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = ((mq >> k) & 1u) ? g[k] : 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           acc[j][0][k] += g[k];
@@ -1231,7 +1312,16 @@ static int bn_bwd_reduce(const void* dz, int lddz, const void* z, int ldz, const
     YV1_LAUNCH_CHECK();
     return YV1_OK;
   }
-  if (C / 8 > TX) hipLaunchKernelGGL(k_bn_bwd_reduce<2>, dim3(blocks), dim3(256), lds, stream, a, TX);
+  if (!pool_idx) {
+#define YV1_BWD_REDUCE_S(MODE_)                                                                                 \
+    if (mask_mode == MODE_) {                                                                                   \
+      if (C / 8 > TX) hipLaunchKernelGGL((k_bn_bwd_reduce_s<2, MODE_>), dim3(blocks), dim3(256), lds, stream, a, TX);  \
+      else hipLaunchKernelGGL((k_bn_bwd_reduce_s<1, MODE_>), dim3(blocks), dim3(256), lds, stream, a, TX);      \
+    }
+    YV1_BWD_REDUCE_S(0) YV1_BWD_REDUCE_S(1) YV1_BWD_REDUCE_S(2) YV1_BWD_REDUCE_S(3)
+#undef YV1_BWD_REDUCE_S
+  }
+  else if (C / 8 > TX) hipLaunchKernelGGL(k_bn_bwd_reduce<2>, dim3(blocks), dim3(256), lds, stream, a, TX);
   else hipLaunchKernelGGL(k_bn_bwd_reduce<1>, dim3(blocks), dim3(256), lds, stream, a, TX);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
@@ -1334,8 +1424,13 @@ extern "C" int yv1_bn_bwd_reduce_dual(const void* dz, int lddz, const void* z, i
   a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
   a.mean = mean; a.invstd = invstd; a.npix = npix; a.C = C; a.pix_per_block = ppb; a.mask_mode = mask_mode; a.part = partials;
   a.y2 = (const bf16_t*)y2; a.ldy2 = ldy2; a.mean2 = mean2; a.invstd2 = invstd2; a.part2 = partials2;
-  if (C / 8 > TX) hipLaunchKernelGGL(k_bn_bwd_reduce_dual<2>, dim3(blocks), dim3(256), lds, stream, a, TX);
-  else hipLaunchKernelGGL(k_bn_bwd_reduce_dual<1>, dim3(blocks), dim3(256), lds, stream, a, TX);
+#define YV1_REDUCE_DUAL(MODE_)                                                                                   \
+  if (mask_mode == MODE_) {                                                                                     \
+    if (C / 8 > TX) hipLaunchKernelGGL((k_bn_bwd_reduce_dual<2, MODE_>), dim3(blocks), dim3(256), lds, stream, a, TX);  \
+    else hipLaunchKernelGGL((k_bn_bwd_reduce_dual<1, MODE_>), dim3(blocks), dim3(256), lds, stream, a, TX);     \
+  }
+  YV1_REDUCE_DUAL(0) YV1_REDUCE_DUAL(1) YV1_REDUCE_DUAL(3)
+#undef YV1_REDUCE_DUAL
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
