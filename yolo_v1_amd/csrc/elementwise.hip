@@ -757,11 +757,19 @@ __global__ void __launch_bounds__(256, 4) k_bn_bwd_apply_pool2(BwdArgs a) {
       bwd_apply_coeffs(a, c8, k1, ka, kb);
       if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
     }
+    // the four BatchNorm inputs of the patch up front: a load issued after the previous pixel's store waits for it (the
+    // compiler cannot prove y and dy apart) -- four memory round trips per patch instead of one
+    u32x4 yq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t p = ((size_t)n * a.pH + 2 * pa + (q >> 1)) * a.pW + 2 * pb + (q & 1);
+      yq[q] = *reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const size_t p = ((size_t)n * a.pH + 2 * pa + (q >> 1)) * a.pW + 2 * pb + (q & 1);
       float yv[8], o[8];
-      unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8), yv);
+      unpack8(yq[q], yv);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float gk = (a.mask_mode == 2 && !(yv[k] * sc[k] + sh[k] > 0.f)) ? 0.f : g[q][k];
