@@ -62,8 +62,18 @@ def test_full_size_forward_vs_oracle_and_training_step(backbone, S, max_tol, mea
     opt = FusedSGD(net.parameters(), lr=1e-3, momentum=0.99)
     crit = YOLOLossV1(N, S, 2, 20, _quiet=True)
     xd, td = images.to(DEV), target.to(DEV)
-    l1 = float(train_step(net, crit, opt, xd, td, 1e-3).item())
-    l2 = float(train_step(net, crit, opt, xd, td, 1e-3).item())
+    import os
+    # YV1_TEST_FULLSIZE_GRAPH=1: the captured step instead.  It segfaulted inside hipGraphLaunch at this point of the suite
+    # while the backward's graph spread over four hardware queues; since the main chain stays on one queue (DESIGN.md
+    # section 5) the whole suite passes with it -- the eager steps stay the default until that is understood, not just observed
+    if os.environ.get("YV1_TEST_FULLSIZE_GRAPH") == "1":
+        from yolo_v1_amd.train import GraphedStep
+        gs = GraphedStep(net, crit, opt, xd, td, None, warmup=1, preserve_state=True)
+        l1 = float(gs(1e-3).item())
+        l2 = float(gs(1e-3).item())
+    else:
+        l1 = float(train_step(net, crit, opt, xd, td, 1e-3).item())
+        l2 = float(train_step(net, crit, opt, xd, td, 1e-3).item())
     assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2
     np.testing.assert_allclose(l1, loss.item(), rtol=1e-5)            # same weights, same batch: the step's loss is the forward's
     assert all(torch.isfinite(p).all() for p in net.parameters())
