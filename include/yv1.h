@@ -140,6 +140,13 @@ int yv1_stats_merge(const float* partials, int rows, int Cseg, float* table, int
 int yv1_bn_finalize(const float* partials, int rows, int C, int ld_partials, float count, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
                     float* invstd, float* scale, float* shift, yv1_stream_t stream);
+/* DenseNet: finalize the first C channels of the shared one-row table [2][ld] of channel sums (OriginDenseNet.py:32-36,
+ * norm1 over the concatenated features) while merging the partial rows seg_part [seg_rows][2][seg_c] of the features
+ * the previous layer produced into table columns [seg_c0, seg_c0+seg_c) -- yv1_stats_merge + yv1_bn_finalize in one launch */
+int yv1_bn_finalize_merged(float* table, int C, int ld, float count, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                           float* scale, float* shift, const float* seg_part, int seg_rows, int seg_c0, int seg_c,
+                           yv1_stream_t stream);
 int yv1_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, yv1_stream_t stream);
 /* z = relu?(scale*y + shift [+ residual | + res_scale*residual + res_shift]); relu_mask (nullable): uint8

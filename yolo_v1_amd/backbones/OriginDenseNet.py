@@ -102,7 +102,9 @@ class DenseNet(HipBackbone):
             ops.bn_apply(y1, st2, t2, relu=True)
         stats = ops.conv_fwd(t2, w2, buf.window(cin, self.growth), train)
         if train:
-            ops.stats_merge(stats, table[0], cin)
+            # the new features' statistic rows join the shared table inside the NEXT BatchNorm's finalize launch (the next
+            # layer's norm1, the transition's norm or norm5 -- each reads the table over at least these channels)
+            self._pending_seg = (stats, cin)
         return (layer, cin, st1, t1, y1, st2, t2)
 
     def transition_forward(self, tr, buf, table, norm):
@@ -167,10 +169,16 @@ class DenseNet(HipBackbone):
         self.refresh_all_weights()
         bns = []
 
+        self._pending_seg = None
+        self._cur_table = None
+
         def norm(stats, count, bn, C=None):
             if train:
                 bns.append(bn)
-                return ops.bn_finalize(stats, count, bn, C)
+                seg = None
+                if stats is self._cur_table and self._pending_seg is not None:  # the block's shared table: merge what is owed
+                    seg, self._pending_seg = self._pending_seg, None
+                return ops.bn_finalize(stats, count, bn, C, seg=seg)
             return ops.bn_eval_state(bn)
 
         w0 = self.cw(F.conv0, stem=True)
@@ -195,6 +203,7 @@ class DenseNet(HipBackbone):
                 table = None
                 if train:
                     table = torch.empty((1, 2, ctot), dtype=torch.float32, device=dev)
+                    self._cur_table = table
                     ops.stats_merge(ops.bn_stats(first), table[0], 0)
                 lrecs = []
                 for li, layer in enumerate(getattr(F, name).layers()):

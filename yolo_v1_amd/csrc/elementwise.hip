@@ -86,11 +86,13 @@ __global__ void __launch_bounds__(1024) k_stats_merge(const float* __restrict__ 
 // through LDS in a fixed order, then lane 0 does the per-channel math.  One launch replaces the former
 // reduce_rows + finalize pair.
 template <int CPB>
-__global__ void __launch_bounds__(1024) k_bn_finalize(const float* __restrict__ part, int rows, int C, int ldp, float count,
+__global__ void __launch_bounds__(1024) k_bn_finalize(const float* part, int rows, int C, int ldp, float count,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float momentum, float* running_mean, float* running_var,
                                                      float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                     float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                                     float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                                     const float* __restrict__ seg_part, int seg_rows, int seg_c0, int seg_c,
+                                                     float* table_out) {
   // CPB channels per workgroup x RL = 1024/CPB row lanes.  CPB 64 reads full 256-B lines; CPB 16 spreads a narrow
   // BatchNorm (C <= 1024) over 4x the workgroups -- these launches are latency-bound, not bandwidth-bound.
   constexpr int RL = 1024 / CPB;
@@ -98,17 +100,24 @@ __global__ void __launch_bounds__(1024) k_bn_finalize(const float* __restrict__ 
   const int tx = threadIdx.x % CPB, ty = threadIdx.x / CPB;
   const int c = blockIdx.x * CPB + tx;
   float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+  // merged form (DenseNet: yv1_bn_finalize_merged): channels [seg_c0, seg_c0 + seg_c) are not in the table yet -- their
+  // sums are still the partial rows [seg_rows][2][seg_c] of the convolution that produced them; they are reduced here
+  // and written into the table for the BatchNorms further down the block
+  const bool seg = seg_part != nullptr && c >= seg_c0 && c < seg_c0 + seg_c;
   if (c < C) {
+    const float* src = seg ? seg_part + (c - seg_c0) : part + c;
+    const size_t rstride = seg ? (size_t)2 * seg_c : (size_t)2 * ldp, qoff = seg ? seg_c : ldp;
+    const int nrows = seg ? seg_rows : rows;
     int r = ty;
-    for (; r + RL < rows; r += 2 * RL) {
-      s0 += part[(size_t)r * 2 * ldp + c];
-      q0 += part[(size_t)r * 2 * ldp + ldp + c];
-      s1 += part[(size_t)(r + RL) * 2 * ldp + c];
-      q1 += part[(size_t)(r + RL) * 2 * ldp + ldp + c];
+    for (; r + RL < nrows; r += 2 * RL) {
+      s0 += src[(size_t)r * rstride];
+      q0 += src[(size_t)r * rstride + qoff];
+      s1 += src[(size_t)(r + RL) * rstride];
+      q1 += src[(size_t)(r + RL) * rstride + qoff];
     }
-    for (; r < rows; r += RL) {
-      s0 += part[(size_t)r * 2 * ldp + c];
-      q0 += part[(size_t)r * 2 * ldp + ldp + c];
+    for (; r < nrows; r += RL) {
+      s0 += src[(size_t)r * rstride];
+      q0 += src[(size_t)r * rstride + qoff];
     }
   }
   red[0][ty][tx] = s0 + s1;
@@ -118,6 +127,7 @@ __global__ void __launch_bounds__(1024) k_bn_finalize(const float* __restrict__ 
   float s = 0.f, ss = 0.f;
 #pragma unroll 16
   for (int j = 0; j < RL; ++j) { s += red[0][j][tx]; ss += red[1][j][tx]; }
+  if (seg) { table_out[c] = s; table_out[ldp + c] = ss; }
   const float mean = s / count;
   float var = ss / count - mean * mean;
   var = var < 0.f ? 0.f : var;
@@ -1195,22 +1205,47 @@ static int finalize_cpb(int C) {
   return C <= maxc ? cpb : 64;
 }
 
-extern "C" int yv1_bn_finalize(const float* partials, int rows, int C, int ld_partials, float count, const float* gamma,
-                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                               float* mean, float* invstd, float* scale, float* shift, hipStream_t stream) {
+static int bn_finalize(const float* partials, int rows, int C, int ld_partials, float count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                       float* invstd, float* scale, float* shift, const float* seg_part, int seg_rows, int seg_c0, int seg_c,
+                       float* table_out, hipStream_t stream) {
   if (!partials || rows <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return YV1_ERR_BAD_ARG;
   const int cpb = finalize_cpb(C);
   if (cpb == 8)
     hipLaunchKernelGGL(k_bn_finalize<8>, dim3((C + 7) / 8), dim3(1024), 0, stream, partials, rows, C, ld_partials, count, gamma,
-                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, seg_part, seg_rows, seg_c0,
+                       seg_c, table_out);
   else if (cpb == 16)
     hipLaunchKernelGGL(k_bn_finalize<16>, dim3((C + 15) / 16), dim3(1024), 0, stream, partials, rows, C, ld_partials, count, gamma,
-                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, seg_part, seg_rows, seg_c0,
+                       seg_c, table_out);
   else
     hipLaunchKernelGGL(k_bn_finalize<64>, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, rows, C, ld_partials, count, gamma,
-                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, seg_part, seg_rows, seg_c0,
+                       seg_c, table_out);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
+}
+
+extern "C" int yv1_bn_finalize(const float* partials, int rows, int C, int ld_partials, float count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                               float* mean, float* invstd, float* scale, float* shift, hipStream_t stream) {
+  return bn_finalize(partials, rows, C, ld_partials, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                     scale, shift, nullptr, 0, 0, 0, nullptr, stream);
+}
+
+// DenseNet (OriginDenseNet.py:32-36: every layer's norm1 acts on the concatenation of all earlier features): the shared
+// one-row table [2][ld] of channel sums / sums of squares is finalized for the first C channels, of which
+// [seg_c0, seg_c0 + seg_c) -- the features the previous layer just produced -- are still that convolution's partial rows
+// seg_part [seg_rows][2][seg_c]: they are summed here AND written into the table (what yv1_stats_merge + yv1_bn_finalize
+// do in two launches).  seg_c0 + seg_c <= C.
+extern "C" int yv1_bn_finalize_merged(float* table, int C, int ld, float count, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                      float* invstd, float* scale, float* shift, const float* seg_part, int seg_rows,
+                                      int seg_c0, int seg_c, hipStream_t stream) {
+  if (!seg_part || seg_rows <= 0 || seg_c <= 0 || seg_c0 < 0 || seg_c0 + seg_c > C || C > ld) return YV1_ERR_BAD_ARG;
+  return bn_finalize(table, 1, C, ld, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
+                     seg_part, seg_rows, seg_c0, seg_c, table, stream);
 }
 
 extern "C" int yv1_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,

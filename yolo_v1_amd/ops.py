@@ -483,13 +483,27 @@ def _shrink_partials(part, rows, W, dev):
     return out, r2
 
 
-def bn_finalize(stats, count, bn, C=None, training=True):
-    """stats [rows][2][ld] partials -> BNState (and running-stat update of module ``bn``)."""
+def bn_finalize(stats, count, bn, C=None, training=True, seg=None):
+    """stats [rows][2][ld] partials -> BNState (and running-stat update of module ``bn``).
+    ``seg`` = (part [rows][2][Cseg], c0) with a one-row ``stats`` table (DenseNet): the table's columns [c0, c0+Cseg) are
+    still the partial rows of the convolution that produced those features -- merged into the table by the same launch."""
     dev = stats.device
     rows, _, ld = stats.shape
     C = C or bn.num_features
     st = BNState(C, dev)
     st.count = count
+    if seg is not None:
+        part, c0 = seg
+        prow, _, cseg = part.shape
+        if rows != 1 or c0 + cseg > C:
+            raise ValueError("bn_finalize: a merged segment needs the one-row table and must lie inside the finalized channels")
+        part, prow = _shrink_partials(part, prow, 2 * cseg, dev)
+        check(lib().yv1_bn_finalize_merged(ptr(stats), C, ld, float(count), ptr(bn.weight), ptr(bn.bias), BN_EPS, BN_MOMENTUM,
+                                           ptr(bn.running_mean) if training else None,
+                                           ptr(bn.running_var) if training else None, ptr(st.mean), ptr(st.invstd),
+                                           ptr(st.scale), ptr(st.shift), ptr(part), prow, c0, cseg, stream_ptr(dev)),
+              "yv1_bn_finalize_merged")
+        return st
     part, rows = _shrink_partials(stats, rows, 2 * ld, dev)
     check(lib().yv1_bn_finalize(ptr(part), rows, C, ld, float(count), ptr(bn.weight), ptr(bn.bias), BN_EPS, BN_MOMENTUM,
                                 ptr(bn.running_mean) if training else None, ptr(bn.running_var) if training else None,
