@@ -208,6 +208,7 @@ def other_training_config(backbone, S, batch, device, fp8_forward=False, steps=8
            "dtype": "fp8-e4m3 forward GEMMs, bf16 backward" if fp8_forward else "bf16",
            "value": round(batch / ms * 1e3, 1), "unit": "images/sec", "ms_per_step": round(ms, 3), "steps": steps,
            "achieved_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 5)}
+    graphed.close()            # the hipGraphExec, its private pool (all saved activations) and its streams go back NOW
     del graphed, net, opt, loss_layer
     torch.cuda.empty_cache()
     return out
@@ -249,6 +250,7 @@ def other_eval_config(S, batch, device, iters=10):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         res[name] = {"value": round(batch / ms * 1e3, 1), "unit": "images/sec", "ms_per_batch": round(ms, 3)}
+        g.reset()
         del g
     res["workload"] = "ResNet-50 448x448 S=%d eval-mode forward + batched decoder/NMS, batch %d, hipGraph replay" % (S, batch)
     del eng, net
@@ -409,7 +411,8 @@ def main():
         headline = args.backbone == "resnet" and args.S == 7 and not args.fp8_forward
         if world == 1 and args.other_configs and headline and graphed is not None:
             # BASELINE.json configs 3 and 5 in the same run (driver-visible), after the headline timed region
-            del graphed
+            graphed.close()                # destroy the headline step's hipGraphExec before the next captures (train.GraphedStep)
+            graphed = None
             torch.cuda.empty_cache()
             oc = {}
             for key, kw in (("densenet121_S7", dict(backbone="densenet", S=7)),

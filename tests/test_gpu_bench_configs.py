@@ -49,8 +49,13 @@ SEEN = {}
 
 
 def _note(kind, shape, cfgs):
+    """Keys are the strings csrc/cfglog.hip reports, INCLUDING the split-K factor of a slab reduction: the step's
+    weight gradients go through yv1_conv2d_wgrad_shared_nhwc_bf16 (narrower split-K beside the main stream's kernels), the
+    stand-alone call through yv1_conv2d_wgrad_nhwc_bf16 -- same templates, different slab counts, and the checklist must
+    tell them apart."""
     for c in cfgs:
-        SEEN.setdefault(c.split(" splitK")[0], []).append("%s %s" % (kind, shape))
+        key = c + (" [shared entry]" if kind == "wgrad-shared" else "")
+        SEEN.setdefault(key, []).append("%s %s" % (kind, shape))
 
 
 def bf(x):
@@ -125,7 +130,9 @@ def _run_case(Cin, Cout, k, stride, H, ld, tag):
     F.conv2d(xr, w, stride=stride, padding=pad).backward(gy[imgs])
     _cmp(dxa.t[imgs], xr.grad.permute(0, 2, 3, 1), 1e-2, 1e-2, shape + " dgrad " + ";".join(cd))
 
-    # ---- weight gradient: full reduction over the batch
+    # ---- weight gradient: full reduction over the batch, through BOTH entry points: the stand-alone one
+    # (yv1_conv2d_wgrad_nhwc_bf16) and the one the training step dispatches on its side stream
+    # (yv1_conv2d_wgrad_shared_nhwc_bf16: narrower split-K, other slab counts, other k_reduce_slabs splitK)
     gw = ops.conv_wgrad(xa, dya, cw)
     cwg = _lib.last_config()
     torch.cuda.synchronize()
@@ -133,7 +140,15 @@ def _run_case(Cin, Cout, k, stride, H, ld, tag):
     wr = w.clone().requires_grad_(True)
     F.conv2d(x, wr, stride=stride, padding=pad).backward(gy)
     _cmp(gw, wr.grad, 2e-3, 2e-3, shape + " wgrad " + ";".join(cwg))
-    return cf + cd + cwg
+    side = ops.SideStream(DEV)
+    assert side.side is not None
+    gws = ops.conv_wgrad(xa, dya, cw, side)
+    cws = _lib.last_config()
+    side.join()
+    torch.cuda.synchronize()
+    _note("wgrad-shared", shape, cws)
+    _cmp(gws, wr.grad, 2e-3, 2e-3, shape + " wgrad (shared entry) " + ";".join(cws))
+    return cf + cd + cwg + cws
 
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,H", RESNET)
@@ -220,6 +235,9 @@ def test_zz_every_bench_template_was_covered():
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_kernel_templates.json")))
     lines = ["%-44s %s" % (k, SEEN[k][0] + (" (+%d more)" % (len(SEEN[k]) - 1) if len(SEEN[k]) > 1 else "")) for k in sorted(SEEN)]
     print("\nkernel template                               covered by\n" + "\n".join(lines))
+    if os.environ.get("YV1_DUMP_TEMPLATES"):          # maintenance: what this run saw, to refresh the committed checklist
+        json.dump({k: sorted(set(v.split(" ")[0] for v in SEEN[k])) for k in sorted(SEEN)},
+                  open(os.environ["YV1_DUMP_TEMPLATES"], "w"), indent=1)
     missing = [t for t in want["bench_dispatched"] if t not in SEEN]
     assert not missing, "templates the bench dispatches without a batch-64 element-wise test: %s" % missing
     unknown = [t for t in SEEN if t not in want["bench_dispatched"] and t not in want["other_known"]]

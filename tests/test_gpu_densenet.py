@@ -244,6 +244,7 @@ def test_densenet_graphed_steps_single_and_data_parallel_are_bitwise_the_eager_s
             pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
             for k in ("features.conv0.weight", "features.denseblock2.denselayer5.conv2.weight", "features.norm5.weight", "bn_end.bias"):
                 assert torch.equal(pa[k], pb[k]), (with_sync, k)
+            gs.close()
     finally:
         if created:
             dist.destroy_process_group()

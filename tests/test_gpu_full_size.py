@@ -6,8 +6,9 @@ storage emulated) in seconds: DenseNet-121 S=7 (OriginDenseNet.py:114-129, 1.5 T
 (OriginResNet.py:173-195, 2.1 TFLOP).  The HIP executors run at the tile configurations the bench dispatches
 (per-layer element-wise parity of those: test_gpu_bench_configs.py); here the whole network is compared end to end
 with the tolerances of the reduced-size whole-net tests (sigmoid outputs: ResNet max 5e-2 / mean 1e-2, DenseNet max
-2e-1 / mean 4e-2), then two training steps (forward + loss + backward + fused SGD) run at that size: finite gradients
-for every parameter, the first step's loss equals the forward's, the second differs (the weights moved).
+2e-1 / mean 4e-2), then two training steps (forward + loss + backward + fused SGD, captured into a hipGraph and replayed --
+the form bench.py times) run at that size: finite gradients for every parameter, the first step's loss equals the forward's,
+the second differs (the weights moved).
 """
 import numpy as np
 import pytest
@@ -52,28 +53,28 @@ def test_full_size_forward_vs_oracle_and_training_step(backbone, S, max_tol, mea
     ref_loss, _ = ol.yolo_loss(ref, target, S, 2, 20, batch_size=N)
     loss = YOLOLossV1(N, S, 2, 20, _quiet=True)(pred, target.to(DEV))
     np.testing.assert_allclose(loss.item(), float(ref_loss), rtol=5e-2)
-    # one training step at full size (eager launches; the hipGraph replay of the same step at this size is what bench.py
-    # times -- captured here as well, on top of the ~20 graphs the suite has already built in this process, the HIP runtime
-    # segfaulted inside hipGraphLaunch: a resource limit of the runtime, not of the step)
+    # two training steps at full size, CAPTURED (one hipGraph: forward + loss + backward + fused SGD) and replayed -- the
+    # form bench.py times and train.main runs.  Round 2 this capture segfaulted inside hipGraphLaunch at this point of the
+    # suite; DESIGN.md section 4 has the diagnosis (hipGraphExec objects of earlier tests still alive) -- every captured
+    # step is now closed deterministically, and the number of execs still alive is printed and bounded here.
     net.load_state_dict(P, strict=True)
     from yolo_v1_amd import ops
-    from yolo_v1_amd.train import train_step
+    from yolo_v1_amd.train import GraphedStep
+    import gc
+    gc.collect()
+    live = GraphedStep.live_graphs()
+    raw = sum(1 for o in gc.get_objects() if isinstance(o, torch.cuda.CUDAGraph))
+    print("hipGraphExec objects alive before the full-size capture: %d owned by GraphedStep, %d torch.cuda.CUDAGraph in all"
+          % (live, raw))
+    assert live == 0, "an earlier test left %d captured training steps alive (GraphedStep.close() missing)" % live
     ops.bump_weight_epoch()
     opt = FusedSGD(net.parameters(), lr=1e-3, momentum=0.99)
     crit = YOLOLossV1(N, S, 2, 20, _quiet=True)
     xd, td = images.to(DEV), target.to(DEV)
-    import os
-    # YV1_TEST_FULLSIZE_GRAPH=1: the captured step instead.  It segfaulted inside hipGraphLaunch at this point of the suite
-    # while the backward's graph spread over four hardware queues; since the main chain stays on one queue (DESIGN.md
-    # section 5) the whole suite passes with it -- the eager steps stay the default until that is understood, not just observed
-    if os.environ.get("YV1_TEST_FULLSIZE_GRAPH") == "1":
-        from yolo_v1_amd.train import GraphedStep
-        gs = GraphedStep(net, crit, opt, xd, td, None, warmup=1, preserve_state=True)
+    with GraphedStep(net, crit, opt, xd, td, None, warmup=1, preserve_state=True) as gs:
         l1 = float(gs(1e-3).item())
         l2 = float(gs(1e-3).item())
-    else:
-        l1 = float(train_step(net, crit, opt, xd, td, 1e-3).item())
-        l2 = float(train_step(net, crit, opt, xd, td, 1e-3).item())
+    assert GraphedStep.live_graphs() == 0
     assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2
     np.testing.assert_allclose(l1, loss.item(), rtol=1e-5)            # same weights, same batch: the step's loss is the forward's
     assert all(torch.isfinite(p).all() for p in net.parameters())

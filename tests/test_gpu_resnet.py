@@ -344,6 +344,11 @@ def test_graphed_step_is_bitwise_the_eager_step():
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     for k in ("conv1.weight", "layer3.1.conv2.weight", "bn_end.bias"):
         assert torch.equal(pa[k], pb[k]), k
+    from yolo_v1_amd.train import GraphedStep as _GS
+    n_live = _GS.live_graphs()
+    gs.close()                                                  # deterministic teardown: the exec is gone NOW
+    assert _GS.live_graphs() == n_live - 1 and gs.graph is None and gs.net is None
+    gs.close()                                                  # idempotent
     # an eager forward after graph replays sees the updated weights (bf16 shadow copies refreshed)
     a.eval(); b.eval()
     with torch.no_grad():
@@ -398,6 +403,7 @@ def test_data_parallel_graphed_step_two_graphs_is_bitwise_the_eager_step():
             # eager warm-up: one bucket; every replayed step: one collective per phase boundary + one for the rest
             assert sync.buckets_issued == 1 + len(gs.graphs) * (len(lrs) - 1)
             assert sync.in_place_buckets == sync.buckets_issued                            # all inside the gradient arena
+            gs.close()
     finally:
         if created:
             dist.destroy_process_group()

@@ -63,6 +63,8 @@ def _worker(rank, world, port, q, mode):
         assert sync.in_place_buckets == sync.buckets_issued and sync.buckets_issued > 0, (sync.in_place_buckets, sync.buckets_issued)
         assert all(p.grad.untyped_storage().data_ptr() == gs.arena.flat.untyped_storage().data_ptr() for p in net.parameters())
     q.put((rank, losses, _pick(net), sync.buckets_issued))
+    if mode == "graphed":
+        gs.close()
     dist.destroy_process_group()
 
 

@@ -403,3 +403,65 @@ def test_bench_self_launches_ranks_before_touching_the_gpu():
     assert r.returncode != 0
     assert "launch with torch.distributed.run" not in r.stderr
     assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rank-0 gate between epochs (only rank 0 validates; the others must not sit in a collective meanwhile)
+def _gate_worker(rank, world, port, q, _tag=None):
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from yolo_v1_amd import distributed as ydist
+    r, w, _ = ydist.init_from_env(backend="gloo", timeout_s=1234)
+    assert (r, w) == (rank, world)
+    t0 = time.perf_counter()
+    if rank == 0:
+        time.sleep(1.5)                               # "validation + checkpoint" on rank 0 only
+    ydist.rank0_gate("epoch0", rank, world)
+    waited = time.perf_counter() - t0
+    ydist.rank0_gate("epoch1", rank, world) if rank == 0 else None      # a gate opened early is simply passed later
+    if rank == 1:
+        time.sleep(0.3)
+        ydist.rank0_gate("epoch1", rank, world)
+    t = torch.ones(1) * (rank + 1)
+    dist.all_reduce(t)                                # the group still works afterwards
+    q.put((rank, waited, float(t)))
+    dist.destroy_process_group()
+
+
+def test_rank0_gate_gloo_world2_holds_the_other_rank_without_a_collective():
+    (_, w0, s0), (_, w1, s1) = _spawn2(_gate_worker, "gate")
+    assert w1 >= 1.0, w1                              # rank 1 waited for rank 0's "validation"
+    assert s0 == s1 == 3.0
+
+
+def test_rank0_gate_is_a_no_op_for_one_rank():
+    from yolo_v1_amd import distributed as ydist
+    ydist.rank0_gate("anything", 0, 1)
+
+
+def test_grad_arena_is_sized_from_padded_conv_requests():
+    """conv_wgrad asks for Opad*taps*Ipad elements (output channels rounded up to 32): a network with several
+    padded convolutions must fit its arena -- sized from the requests, no fixed slack."""
+    import torch.nn as nn
+    from yolo_v1_amd import ops
+    from yolo_v1_amd.engine import ConvParam, HipBackbone
+
+    class Net(HipBackbone):
+        def __init__(self):
+            super().__init__()
+            self.stem = ConvParam(3, 64, 7, 2, 3)
+            self.heads = nn.ModuleList([ConvParam(2048, 30, 1) for _ in range(40)])     # 40 x 2 padded rows x 2048
+            self.wide = ConvParam(64, 33, 3, 1, 1)                                       # 33 -> 64 output rows
+            self.bn = nn.BatchNorm2d(30)
+
+    net = Net()
+    arena = ops.GradArena(net, "cpu")
+    for m in net.heads:
+        assert arena.get(m.weight, 32 * 1 * 2048).numel() == 32 * 2048
+    assert arena.get(net.wide.weight, 64 * 9 * 64).numel() == 64 * 9 * 64
+    assert arena.get(net.stem.weight, 64 * 7 * 7 * 3).numel() == 64 * 147
+    assert arena.get(net.bn.weight, 30).numel() == 30 and arena.get(net.bn.bias, 30).numel() == 30
+    assert arena.top == arena.flat.numel()                                                # exactly what was requested
+    with pytest.raises(Exception):
+        arena.get(nn.Parameter(torch.zeros(8)), 8)

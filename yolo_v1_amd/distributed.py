@@ -21,9 +21,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, timeout_s=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE (torch.distributed.run contract).  Returns
-    (rank, world_size, device)."""
+    (rank, world_size, device).  ``timeout_s``: collective timeout of the process group (default: the backend's, 10 min
+    for RCCL) -- train.main raises it when rank 0 validates between epochs while the other ranks already wait."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -36,8 +37,28 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {"device_id": device} if use_cuda else {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
         dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world, **kw)
     return rank, world, device
+
+
+def rank0_gate(tag, rank, world, timeout_s=6 * 3600):
+    """Host-side gate on the rendezvous store (NOT a collective): rank 0 calls it when it is done with ``tag`` (e.g. the
+    per-epoch validation + checkpoint, train.py:187-209, which only rank 0 runs -- DataParallel's single replica), every
+    other rank blocks here until then.  Without it the other ranks enter the next epoch, enqueue their first all-reduce and
+    sit in it while rank 0 still walks the validation set; past the process group's timeout the RCCL watchdog would abort
+    the job.  A store wait has no watchdog and holds no GPU work."""
+    if world <= 1 or not dist.is_initialized():
+        return
+    import datetime
+    store = dist.distributed_c10d._get_default_store()
+    key = "yv1_gate/%s" % tag
+    if rank == 0:
+        store.set(key, "1")
+    else:
+        store.wait([key], datetime.timedelta(seconds=float(timeout_s)))
 
 
 def _flat_memory_view(t):

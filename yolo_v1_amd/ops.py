@@ -367,7 +367,17 @@ class GradArena:
     (GradSync without an arena concatenates and scatters: two passes over 165 MB per step for ResNet-50)."""
 
     def __init__(self, net, device):
-        total = sum((p.numel() + 3) // 4 * 4 for p in net.parameters()) + (1 << 18)      # + room for padded output rows
+        # sized from what the gradient-producing ops will actually request: a convolution weight asks for its PADDED
+        # shape (conv_wgrad: Opad x taps x Ipad -- output channels rounded up to 32, e.g. the 30-channel head; the stem
+        # asks for O x 7 x 7 x 3), every other parameter for its own element count
+        from .engine import ConvParam
+        conv_params = {}
+        for m in net.modules():
+            if isinstance(m, ConvParam):
+                O, I = m.weight.shape[0], m.weight.shape[1]
+                opad = (O + 31) // 32 * 32
+                conv_params[id(m.weight)] = m.weight.numel() if I == 3 else opad * m.kernel_size * m.kernel_size * I
+        total = sum((conv_params.get(id(p), p.numel()) + 3) // 4 * 4 for p in net.parameters())
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.ranges = {}                   # id(param) -> (offset, numel)
         self.top = 0

@@ -13,6 +13,7 @@ Evaluation (train.py:187-198) lives in ``yolo_v1_amd.eval``.
 import argparse
 import os
 import time
+import weakref
 
 import torch
 
@@ -92,7 +93,55 @@ class GraphedStep:
     layer1, stem: 6 MB) follow in one more collective, then the fused optimizer step.  Gradients live in one flat arena
     (``ops.GradArena``), so every collective runs in place on a contiguous range.  Executors without a phase
     boundary (DenseNet-121: 38 MB of gradients) use one graph and one collective.  ``YV1_DP_PHASES`` = 1 / 2 / 3 graphs.
+
+    Lifetime: a captured step owns hipGraphExec objects, and the HIP runtime torch ships gives EVERY exec whose graph forks
+    (the weight-gradient side stream) parallel streams of its own, plus a kernel-argument pool and the graph's private
+    memory pool (all saved activations: ~23 GB for ResNet-50 at batch 64).  None of that is returned before the exec is
+    destroyed, and Python only destroys it when the last reference goes -- which for an object reachable from a frame,
+    a closure or an autograd graph means "at some later garbage collection".  ``close()`` (or ``with GraphedStep(...) as
+    step:``) releases everything deterministically; a process that builds one captured step after another (bench.py's
+    ``other_configs``, a train-then-evaluate script, the test suite) must call it.  ``GraphedStep.live_graphs()`` counts the
+    execs that are still alive in this process (DESIGN.md section 4 has the fault this was found through).
     """
+    _LIVE = weakref.WeakSet()
+
+    @classmethod
+    def live_graphs(cls):
+        """hipGraphExec objects owned by GraphedStep instances that have not been closed / collected yet."""
+        return sum(len(g._all_graphs()) for g in list(cls._LIVE))
+
+    def _all_graphs(self):
+        gs = list(getattr(self, "graphs", None) or [])
+        g = getattr(self, "graph", None)
+        if g is not None and not any(g is x for x in gs):
+            gs.append(g)
+        return gs
+
+    def close(self):
+        """Destroys the hipGraphExec objects (``CUDAGraph.reset()``: the runtime's per-exec streams, argument pools and
+        the private memory pool go back now, not at the next garbage collection) and drops every reference this object
+        holds -- the static buffers, the network, the gradient arena.  Idempotent; the object is unusable afterwards."""
+        graphs = self._all_graphs()
+        if graphs and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for g in graphs:
+            g.reset()
+        self.graphs, self.graph, self.graph2 = [], None, None
+        self.loss = None
+        self.phases, self.phase1 = [], None
+        if getattr(self, "sync", None) is not None and getattr(self.sync, "arena", None) is self.arena:
+            self.sync.arena = None
+        self.arena = None
+        self.net = self.loss_layer = self.opt = self.sync = None
+        self.images = self.target = None
+        GraphedStep._LIVE.discard(self)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __init__(self, net, loss_layer, optimizer, images, target, grad_sync=None, warmup=3, two_phase=None,
                  preserve_state=False):
@@ -105,6 +154,8 @@ class GraphedStep:
             raise TypeError("GraphedStep needs yolo_v1_amd.optim.FusedSGD (device-side learning rate)")
         self.net, self.loss_layer, self.opt, self.sync = net, loss_layer, optimizer, grad_sync
         self.images, self.target = images, target
+        self.graph = self.graph2 = self.loss = None
+        GraphedStep._LIVE.add(self)
         self.loss_layer.quiet = True
         self.in_graph_step = grad_sync is None
         # measured with a 1-rank RCCL group: a third graph (boundary after layer3) costs 0.4 ms per step -- the boundary
@@ -200,21 +251,37 @@ class GraphedStep:
         torch.cuda.synchronize()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
-            self.graphs[0].capture_begin()
-            try:
-                seen = set()
+            # ``state`` instead of attributes of self: the callback handed to the backward executor must not keep this object
+            # alive (it only needs the lists it fills), and ``open`` says whether a capture is in progress, so that an
+            # exception between two captures is re-raised as it is instead of being buried under a second capture_end()
+            state = {"graphs": self.graphs, "phases": self.phases, "seen": set(), "open": False}
+            state["graphs"][0].capture_begin()
+            state["open"] = True
 
-                def boundary(grads):
-                    # gradients finished since the previous boundary; end this graph, open the next one in the same pool
-                    self.phases.append([(p, g) for p, g in grads.items() if id(p) not in seen])
-                    seen.update(id(p) for p in grads)
-                    self.graphs[-1].capture_end()
-                    nxt = torch.cuda.CUDAGraph()
-                    nxt.capture_begin(pool=self.graphs[0].pool())
-                    self.graphs.append(nxt)
+            def boundary(grads, state=state):
+                # gradients finished since the previous boundary; end this graph, open the next one in the same pool
+                seen = state["seen"]
+                state["phases"].append([(p, g) for p, g in grads.items() if id(p) not in seen])
+                seen.update(id(p) for p in grads)
+                state["graphs"][-1].capture_end()
+                state["open"] = False
+                nxt = torch.cuda.CUDAGraph()
+                nxt.capture_begin(pool=state["graphs"][0].pool())
+                state["graphs"].append(nxt)
+                state["open"] = True
+            try:
                 self.loss = self._direct(boundary if self.two_phase else None)
-            finally:
-                self.graphs[-1].capture_end()
+            except BaseException:
+                if state["open"]:                      # leave capture mode, but let the ORIGINAL error travel
+                    try:
+                        state["graphs"][-1].capture_end()
+                    except Exception:
+                        pass
+                    state["open"] = False
+                raise
+            state["graphs"][-1].capture_end()
+            state["open"] = False
+            state["seen"] = None
         torch.cuda.current_stream().wait_stream(stream)
         if self.two_phase and not self.phases:
             raise RuntimeError("the backward executor never reached its phase boundary")
@@ -244,6 +311,8 @@ class GraphedStep:
 
     def __call__(self, lr):
         from . import ops
+        if self.opt is None:
+            raise RuntimeError("this GraphedStep has been closed")
         self.opt.set_lr(lr)
         if self.in_graph_step:
             self.graph.replay()
@@ -306,7 +375,8 @@ def main(argv=None, return_losses=False):
     from . import ops
     from .utils.YOLODataLoader import synthetic_batch
     from .utils.utils import create_logger
-    rank, world, device = ydist.init_from_env()
+    validating = bool(args.val_list or args.val_synthetic)
+    rank, world, device = ydist.init_from_env(timeout_s=4 * 3600 if validating else None)
     bs = args.batch_size or (16 if args.backbone == 'resnet' else DEFAULTS["batch_size"])      # train.py:68
     opt_name = 'sgd'
     base = args.save_dir or '%s_%s_cellSize%d/' % (args.backbone, opt_name, args.S)              # train.py:91
@@ -424,6 +494,10 @@ def main(argv=None, return_losses=False):
                     checkpoint.save(net, '%s/%s_%s_S%d_best.pth' % (base, args.backbone, opt_name, args.S))
                 net.train()
             checkpoint.save(net, '%s/%s_%s_S%d_yolo.pth' % (base, args.backbone, opt_name, args.S))   # train.py:209
+        # the other ranks wait (on the rendezvous store, not in a collective) until rank 0 has validated and saved
+        ydist.rank0_gate("epoch%d" % epoch, rank, world)
+    if graphed is not None:
+        graphed.close()
     if return_losses:
         return history.cpu().tolist()[:it]
 
