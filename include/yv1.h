@@ -182,6 +182,43 @@ int yv1_bn_bwd_apply_dual(const void* dz, int lddz, const void* z, int ldz, cons
                           const void* y2, int ldy2, const float* mean2, const float* invstd2, const float* k1b,
                           const float* k2b, const float* k3b, void* dy2, int lddy2, long long npix, int C, int mask_mode,
                           yv1_stream_t stream);
+/* Finalize fused into the consuming launch (round 3).  Replaces the launch PAIRS yv1_bn_finalize + yv1_bn_apply(_q8) and
+ * yv1_bn_bwd_finalize + yv1_bn_bwd_apply(_dual) of a training-mode nn.BatchNorm2d (OriginResNet.py:90-105 forward, its
+ * autograd backward): the first workgroups of the grid finalize the partial rows (same arithmetic, fixed summation order),
+ * publish the per-channel coefficients with agent-scope stores and exit; the other workgroups wait for them, then stream the
+ * tensor.  `sync`: TWO zero-initialised unsigned words owned by this launch until it completes (the kernel leaves them
+ * zero again, so a captured graph replays without a memset); `fault`: one unsigned word the caller checks after a
+ * synchronize -- set to 1 if a consumer gave up waiting (~1 s; the spin's exit condition; never observed).
+ * yv1_bn_finalize_apply: partials [rows][2][ld_partials] of the BatchNorm applied to y; r_partials (nullable) the same for
+ * the BatchNorm of `residual` (projection shortcut; then r_mean..r_shift are outputs), else r_scale / r_shift are inputs
+ * (already final) or NULL (plain residual / none).  rows <= 2048 (pre-reduce longer tables with yv1_reduce_rows). */
+int yv1_bn_finalize_apply(const float* partials, int rows, int ld_partials, float count, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                          float* invstd, float* scale, float* shift, const float* r_partials, int r_rows, int r_ld_partials,
+                          const float* r_gamma, const float* r_beta, float* r_running_mean, float* r_running_var,
+                          float* r_mean, float* r_invstd, float* r_scale, float* r_shift, const void* y, int ldy, void* z,
+                          int ldz, const void* residual, int ldr, long long npix, int C, int relu, void* relu_mask, void* z8,
+                          int ldz8, unsigned* sync, unsigned* fault, yv1_stream_t stream);
+/* DenseNet form (OriginDenseNet.py:32-36, norm1 over the concatenation): yv1_bn_finalize_merged + yv1_bn_apply in one
+ * launch; seg_part may be NULL (plain one-row table: transition norm / norm5 with nothing pending). */
+int yv1_bn_finalize_merged_apply(float* table, int C, int ld, float count, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                                 float* scale, float* shift, const float* seg_part, int seg_rows, int seg_c0, int seg_c,
+                                 const void* y, int ldy, void* z, int ldz, long long npix, int relu, unsigned* sync,
+                                 unsigned* fault, yv1_stream_t stream);
+/* partials [rows][2][C] from yv1_bn_bwd_reduce; k1/k2/k3: scratch [C] each; other arguments as yv1_bn_bwd_apply. */
+int yv1_bn_bwd_finalize_apply(const float* partials, int rows, float count, const float* gamma, float* dgamma, float* dbeta,
+                              float* k1, float* k2, float* k3, const void* dz, int lddz, const void* z, int ldz,
+                              const void* y, int ldy, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, long long npix, int C, int mask_mode, void* dy, int lddy, void* dres,
+                              int lddres, int accumulate, unsigned* sync, unsigned* fault, yv1_stream_t stream);
+/* partials / partials2 from yv1_bn_bwd_reduce_dual; k6: scratch [6][C]; other arguments as yv1_bn_bwd_apply_dual. */
+int yv1_bn_bwd_finalize_apply_dual(const float* partials, const float* partials2, int rows, float count, const float* gamma,
+                                   const float* gamma2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, float* k6,
+                                   const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy,
+                                   const float* mean, const float* invstd, void* dy, int lddy, const void* y2, int ldy2,
+                                   const float* mean2, const float* invstd2, void* dy2, int lddy2, long long npix, int C,
+                                   int mask_mode, unsigned* sync, unsigned* fault, yv1_stream_t stream);
 /* BatchNorm(+ReLU) backward behind the stem's 3x3/2 max pool (OriginResNet.py:174-177, OriginDenseNet.py:120-128; autograd
  * of nn.MaxPool2d + nn.ReLU + nn.BatchNorm2d): dpool [N,OH,OW,C] is the gradient of the pool OUTPUT, pool_idx what
  * yv1_maxpool3x3s2_fwd stored; the pool's backward is gathered on the fly, so the 4x larger gradient of the pool input is

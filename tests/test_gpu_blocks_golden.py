@@ -139,7 +139,11 @@ def _oracle_block(kind, fx, stride=1):
 
 def _fwd_helpers(host):
     from yolo_v1_amd import ops
-    norm = lambda stats, count, bn, C=None: ops.bn_finalize(stats, count, bn, C)
+    def norm(stats, count, bn, C=None, apply=None):           # the executors' hook: statistics -> BNState (+ z = relu(bn(x)))
+        st = ops.bn_finalize(stats, count, bn, C)
+        if apply is not None:
+            ops.bn_apply(apply[0], st, apply[1], relu=True)
+        return st
     conv = lambda xa, x8, cp, ya: ops.conv_fwd(xa, host.cw(cp), ya, True)
     return norm, conv, (lambda a: None)
 

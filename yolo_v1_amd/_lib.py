@@ -67,6 +67,15 @@ SIGNATURES = {
     "yv1_bn_finalize_merged": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i,
                                      c_p]),
     "yv1_bn_eval_coeffs": (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
+    "yv1_bn_finalize_apply": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p,
+                                    c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                    c_p, c_i, c_p, c_i, c_p, c_i, c_ll, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "yv1_bn_finalize_merged_apply": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i,
+                                           c_p, c_i, c_p, c_i, c_ll, c_i, c_p, c_p, c_p]),
+    "yv1_bn_bwd_finalize_apply": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p,
+                                        c_p, c_ll, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "yv1_bn_bwd_finalize_apply_dual": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i,
+                                             c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_ll, c_i, c_i, c_p, c_p, c_p]),
     "yv1_bn_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p]),
     "yv1_bn_apply_q8": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_i, c_p]),
     "yv1_bn_reduce_rows": (c_i, [c_ll, c_i]),

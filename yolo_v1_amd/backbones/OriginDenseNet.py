@@ -87,9 +87,8 @@ class DenseNet(HipBackbone):
         N, h, w = buf.N, buf.H, buf.W
         w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
         xin = buf.window(0, cin)
-        st1 = norm(table, buf.npix, layer.norm1, cin)
         t1 = ops.new_act(N, h, w, cin, dev)
-        ops.bn_apply(xin, st1, t1, relu=True)
+        st1 = norm(table, buf.npix, layer.norm1, cin, apply=(xin, t1))
         t2 = ops.new_act(N, h, w, w1.Opad, dev)
         if not train and self.fused_eval:
             # eval(): norm2 + ReLU ride in the 1x1 convolution's epilogue (norm1 acts on the concat input
@@ -98,8 +97,7 @@ class DenseNet(HipBackbone):
             ops.conv_fwd_bn_act(t1, w1, t2, ops.bn_eval_state(layer.norm2), relu=True)
         else:
             y1 = ops.new_act(N, h, w, w1.Opad, dev)
-            st2 = norm(ops.conv_fwd(t1, w1, y1, train), y1.npix, layer.norm2)
-            ops.bn_apply(y1, st2, t2, relu=True)
+            st2 = norm(ops.conv_fwd(t1, w1, y1, train), y1.npix, layer.norm2, apply=(y1, t2))
         stats = ops.conv_fwd(t2, w2, buf.window(cin, self.growth), train)
         if train:
             # the new features' statistic rows join the shared table inside the NEXT BatchNorm's finalize launch (the next
@@ -112,9 +110,8 @@ class DenseNet(HipBackbone):
         dev = buf.t.device
         cin = buf.C
         wc = self.cw(tr.conv)
-        st = norm(table, buf.npix, tr.norm, cin)
         t = ops.new_act(buf.N, buf.H, buf.W, cin, dev)
-        ops.bn_apply(buf, st, t, relu=True)
+        st = norm(table, buf.npix, tr.norm, cin, apply=(buf, t))
         yc = ops.new_act(buf.N, buf.H, buf.W, wc.Opad, dev)
         ops.conv_fwd(t, wc, yc, False)
         return ("trans", tr, buf, st, t, yc)
@@ -172,14 +169,25 @@ class DenseNet(HipBackbone):
         self._pending_seg = None
         self._cur_table = None
 
-        def norm(stats, count, bn, C=None):
+        def norm(stats, count, bn, C=None, apply=None):
+            """BatchNorm statistics -> BNState; with ``apply`` = (x, z) also z = relu(bn(x)) -- in training mode finalize and
+            apply are ONE launch (ops.BN_FUSED)."""
             if train:
                 bns.append(bn)
                 seg = None
-                if stats is self._cur_table and self._pending_seg is not None:  # the block's shared table: merge what is owed
+                on_table = stats is self._cur_table
+                if on_table and self._pending_seg is not None:  # the block's shared table: merge what is owed
                     seg, self._pending_seg = self._pending_seg, None
-                return ops.bn_finalize(stats, count, bn, C, seg=seg)
-            return ops.bn_eval_state(bn)
+                if apply is not None and ops.BN_FUSED:
+                    if on_table:
+                        return ops.bn_finalize_merged_apply(stats, count, bn, C or bn.num_features, apply[0], apply[1], seg=seg)
+                    return ops.bn_finalize_apply(stats, count, bn, apply[0], apply[1], relu=True, C=C)[0]
+                st = ops.bn_finalize(stats, count, bn, C, seg=seg)
+            else:
+                st = ops.bn_eval_state(bn)
+            if apply is not None:
+                ops.bn_apply(apply[0], st, apply[1], relu=True)
+            return st
 
         w0 = self.cw(F.conv0, stem=True)
         xp = ops.pack_input(images)
@@ -219,9 +227,8 @@ class DenseNet(HipBackbone):
                 pending_pool = ("avg", yc)
                 h, w = h // 2, w // 2
 
-        st5 = norm(table, buf.npix, F.norm5, buf.C)
         t5 = ops.new_act(N, h, w, buf.C, dev)
-        ops.bn_apply(buf, st5, t5, relu=True)
+        st5 = norm(table, buf.npix, F.norm5, buf.C, apply=(buf, t5))
         wh = self.cw(self.layer6)
         yh = ops.new_act(N, h, w, wh.Opad, dev)
         sh = norm(ops.conv_fwd(t5, wh, yh, train), yh.npix, self.bn_end, self.out_channels)

@@ -110,33 +110,52 @@ class ResNet(HipBackbone):
         ops.conv_fwd(x, wh, yh, False)
         return ops.head_fwd(yh, ops.bn_eval_state(self.bn_end), self.out_channels)
 
-    def block_forward(self, blk, x, x8, norm, conv, q8, save):
+    def block_forward(self, blk, x, x8, norm, conv, q8, save, norm_apply=None):
         """One Bottleneck (OriginResNet.py:87-107).  ``norm(stats, count, bn)`` -> BNState, ``conv(x, x8, ConvParam, y)``
-        -> statistic partials, ``q8(act)`` -> e4m3 twin or None.  Returns (out, out8, record for block_backward)."""
+        -> statistic partials, ``q8(act)`` -> e4m3 twin or None; ``norm_apply`` (training, ops.BN_FUSED): BatchNorm finalize
+        and apply in ONE launch -- same signature family as ops.bn_finalize_apply.  Returns (out, out8, record for
+        block_backward)."""
         dev = x.t.device
         N = x.N
         planes, cout = blk.conv1.out_channels, blk.conv3.out_channels
         y1 = ops.new_act(N, x.H, x.W, planes, dev)
-        s1 = norm(conv(x, x8, blk.conv1, y1), y1.npix, blk.bn1)
         z1 = ops.new_act(N, x.H, x.W, planes, dev)
         z1_8 = q8(z1)
-        ops.bn_apply(y1, s1, z1, relu=True, z8=z1_8)
+        p1 = conv(x, x8, blk.conv1, y1)
+        if norm_apply is not None:
+            s1, _, _ = norm_apply(p1, blk.bn1, y1, z1, z8=z1_8)
+        else:
+            s1 = norm(p1, y1.npix, blk.bn1)
+            ops.bn_apply(y1, s1, z1, relu=True, z8=z1_8)
         h2, w2_ = ops.conv_out_hw(x.H, x.W, 3, blk.stride, 1)
         y2 = ops.new_act(N, h2, w2_, planes, dev)
-        s2 = norm(conv(z1, z1_8, blk.conv2, y2), y2.npix, blk.bn2)
         z2 = ops.new_act(N, h2, w2_, planes, dev)
         z2_8 = q8(z2)
-        ops.bn_apply(y2, s2, z2, relu=True, z8=z2_8)
+        p2 = conv(z1, z1_8, blk.conv2, y2)
+        if norm_apply is not None:
+            s2, _, _ = norm_apply(p2, blk.bn2, y2, z2, z8=z2_8)
+        else:
+            s2 = norm(p2, y2.npix, blk.bn2)
+            ops.bn_apply(y2, s2, z2, relu=True, z8=z2_8)
         y3 = ops.new_act(N, h2, w2_, cout, dev)
-        s3 = norm(conv(z2, z2_8, blk.conv3, y3), y3.npix, blk.bn3)
+        p3 = conv(z2, z2_8, blk.conv3, y3)
         out = ops.new_act(N, h2, w2_, cout, dev)
         out8 = q8(out)
         yd = sd = None
         if blk.downsample is not None:
             yd = ops.new_act(N, h2, w2_, cout, dev)
-            sd = norm(conv(x, x8, blk.downsample[0], yd), yd.npix, blk.downsample[1])
-            omask = ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd, want_mask=save, z8=out8)
+            pd = conv(x, x8, blk.downsample[0], yd)
+            if norm_apply is not None:            # bn3, the downsample BatchNorm and the block's closing add + ReLU: one launch
+                s3, omask, sd = norm_apply(p3, blk.bn3, y3, out, residual=yd, res_stats=pd, res_bn=blk.downsample[1],
+                                           want_mask=save, z8=out8)
+            else:
+                s3 = norm(p3, y3.npix, blk.bn3)
+                sd = norm(pd, yd.npix, blk.downsample[1])
+                omask = ops.bn_apply(y3, s3, out, relu=True, residual=yd, res_state=sd, want_mask=save, z8=out8)
+        elif norm_apply is not None:
+            s3, omask, _ = norm_apply(p3, blk.bn3, y3, out, residual=x, want_mask=save, z8=out8)
         else:
+            s3 = norm(p3, y3.npix, blk.bn3)
             omask = ops.bn_apply(y3, s3, out, relu=True, residual=x, want_mask=save, z8=out8)
         return out, out8, (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask)
 
@@ -156,6 +175,14 @@ class ResNet(HipBackbone):
                 return ops.bn_finalize(stats, count, bn, C)
             return ops.bn_eval_state(bn)
 
+        def norm_apply(stats, bn, y, z, residual=None, res_stats=None, res_bn=None, want_mask=False, z8=None):
+            bns.append(bn)
+            if res_bn is not None:
+                bns.append(res_bn)
+            return ops.bn_finalize_apply(stats, y.npix, bn, y, z, relu=True, residual=residual, res_stats=res_stats,
+                                         res_bn=res_bn, want_mask=want_mask, z8=z8)
+
+        fused = norm_apply if (train and ops.BN_FUSED) else None
         rec = {"blocks": []}
         # fp8 forward GEMMs (training, BASELINE config 5): every Bottleneck convolution reads e4m3 copies of its input
         # and weights; the copies are written by the BN-apply that produces the activation.  Everything the backward
@@ -183,7 +210,7 @@ class ResNet(HipBackbone):
         rec["stem"] = (xp, y0, s0, None, H, W, pidx)
 
         for blk in self._blocks():
-            x, x8, brec = self.block_forward(blk, x, x8, norm, conv, q8, save)
+            x, x8, brec = self.block_forward(blk, x, x8, norm, conv, q8, save, fused)
             if save:
                 rec["blocks"].append(brec)
 

@@ -672,6 +672,370 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_dual(BwdArgs a) {
   }
 }
 
+// ---- finalize fused into the consuming launch (round 3) ----------------------------------------------------------
+// A training-mode BatchNorm used to be three launches in each direction: producer of the partial rows (the convolution's
+// epilogue / the backward reduction) -> finalize (a 5-7 us kernel on C/16 workgroups) -> apply.  Inside the captured
+// step every dependent launch on the main queue costs its own duration plus ~4.5 us of dispatch gap, and the two
+// finalize kernels of the 53 BatchNorms were 127 of the step's 595 launches.  Here the finalize runs
+// INSIDE the apply launch: the first `producers` workgroups of the grid finalize a slice of channels each (the same
+// arithmetic, in a fixed order: bitwise reproducible), publish the per-channel coefficients and leave; every other
+// workgroup is a consumer: it waits until all producers have published, then streams the tensor exactly as
+// k_bn_apply / k_bn_bwd_apply do.
+//   * No deadlock: producers never wait, and the dispatcher hands out the workgroups of a launch in index order on every
+//     XCD, so a consumer can only be resident (and spinning) when the producers that precede it have been dispatched.
+//     The spin still has an exit condition of its own: after ~1 s it sets the fault word (checked by the host: tests,
+//     bench) and goes on.
+//   * Coherence: the per-XCD L2s are not coherent with each other inside a launch.  Producers publish with agent-scope
+//     (sc1, write-through) stores followed by s_waitcnt vmcnt(0) and ONE agent-scope atomic add per workgroup; consumers
+//     poll with agent-scope loads and fetch the coefficients with agent-scope loads as well -- ONCE per workgroup, into
+//     LDS (1024 workgroups x 256 lanes each fetching their own 64-128 bytes would hammer the 16-64 memory lines that hold
+//     them).  No buffer_wbl2 / buffer_inv: the weight-gradient kernels of the side stream live off their L2 hits.
+//   * The counter pair resets itself: the last consumer through the gate zeroes it (the next launch on that slot is
+//     thousands of launches away), so a captured graph replays without a memset node.
+// MEASURED RESULT (tools/bench_bn_fused.py, MI355X, captured graph): slower than the launch pairs on every ResNet-50
+// shape -- 512 ch @7x7: 24.8 vs 6.7 us forward, 2048 ch @14x14: 76 vs 25 us; the step 24.5 vs 21.65 ms.  The premise was
+// wrong: a dependent launch inside a hipGraph costs 1-2 us and the finalize kernel ~3 us (round 2's 5-7 us + 4.5 us gap
+// were rocprofv3's own overhead), while store(sc1) -> atomic -> poll(sc1) -> atomic -> load(sc1) is five trips to the
+// memory side of an eight-XCD chip, 13-18 us in all.  The host layer therefore keeps the launch pairs
+// (ops.BN_FUSED = False); the fused entry points stay as the tested, bit-identical record of the experiment.
+struct FuseSync {
+  unsigned* ctr;       // [0] producers that have published, [1] consumers that have passed the gate; both zero between launches
+  unsigned* fault;     // set to 1 by a consumer whose wait timed out
+  int producers;       // workgroups [0, producers) finalize, [producers, gridDim.x) consume
+};
+
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void fuse_publish(const FuseSync& s) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores have reached memory
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(s.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void fuse_wait(const FuseSync& s) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(s.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s.producers) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 20)) { atomicOr(s.fault, 1u); break; }        // exit condition: ~1 s
+    }
+    const unsigned consumers = gridDim.x - (unsigned)s.producers;
+    const unsigned d = __hip_atomic_fetch_add(s.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == consumers - 1) {                             // everyone is through: leave the pair zeroed for the next launch
+      __hip_atomic_store(s.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(s.ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+}
+
+// n floats (n % 4 == 0, src 16-byte aligned) published by producers of THIS launch -> LDS, agent scope.  All of a lane's
+// loads are in flight together and waited for once: as a loop of atomic dword loads (which the compiler keeps in order,
+// one memory round trip each) the staging alone cost up to 30 us per launch at C = 2048 -- the first version of this
+// fusion made the step 13 % SLOWER.  Loads and their wait are one asm statement (the outputs are not valid before it).
+__device__ __forceinline__ void stage_agent(float* dst, const float* src, int n) {
+  const int nq = n >> 2;
+  for (int base = 0; base < nq; base += 4 * 256) {
+    float4 v0, v1, v2, v3;
+    const int q0 = base + threadIdx.x, q1 = q0 + 256, q2 = q0 + 512, q3 = q0 + 768;
+    const float* p0 = src + 4 * (q0 < nq ? q0 : 0);
+    const float* p1 = src + 4 * (q1 < nq ? q1 : 0);
+    const float* p2 = src + 4 * (q2 < nq ? q2 : 0);
+    const float* p3 = src + 4 * (q3 < nq ? q3 : 0);
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+    if (q0 < nq) reinterpret_cast<float4*>(dst)[q0] = v0;
+    if (q1 < nq) reinterpret_cast<float4*>(dst)[q1] = v1;
+    if (q2 < nq) reinterpret_cast<float4*>(dst)[q2] = v2;
+    if (q3 < nq) reinterpret_cast<float4*>(dst)[q3] = v3;
+  }
+}
+
+// Forward finalize of FCPB channels per 256-thread workgroup (64 row lanes each): the arithmetic of k_bn_finalize.
+constexpr int FCPB = 4, FRL = 256 / FCPB;
+struct FinFwd {
+  const float* part; int rows, C, ldp; float count;
+  const float* gamma; const float* beta; float eps, momentum;
+  float* rmean; float* rvar; float* mean; float* invstd; float* scale; float* shift;
+  int nblk;                                               // ceil(C / FCPB); 0: nothing to finalize
+  // merged form (DenseNet, see k_bn_finalize): channels [seg_c0, seg_c0 + seg_c) are still the partial rows
+  // seg_part [seg_rows][2][seg_c] of the convolution that produced them; summed here and written into table_out
+  const float* seg_part = nullptr; int seg_rows = 0, seg_c0 = 0, seg_c = 0; float* table_out = nullptr;
+};
+
+__device__ __forceinline__ void fin_fwd_body(const FinFwd& f, int blk, float* red /* [2][FRL][FCPB] */) {
+  const int tx = threadIdx.x % FCPB, ty = threadIdx.x / FCPB;
+  const int c = blk * FCPB + tx;
+  float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+  const bool seg = f.seg_part != nullptr && c >= f.seg_c0 && c < f.seg_c0 + f.seg_c;
+  if (c < f.C) {
+    const float* src = seg ? f.seg_part + (c - f.seg_c0) : f.part + c;
+    const size_t rs = seg ? (size_t)2 * f.seg_c : (size_t)2 * f.ldp, qoff = seg ? f.seg_c : f.ldp;
+    const int nrows = seg ? f.seg_rows : f.rows;
+    int r = ty;
+#pragma unroll 2
+    for (; r + FRL < nrows; r += 2 * FRL) {
+      s0 += src[(size_t)r * rs];
+      q0 += src[(size_t)r * rs + qoff];
+      s1 += src[(size_t)(r + FRL) * rs];
+      q1 += src[(size_t)(r + FRL) * rs + qoff];
+    }
+    for (; r < nrows; r += FRL) {
+      s0 += src[(size_t)r * rs];
+      q0 += src[(size_t)r * rs + qoff];
+    }
+  }
+  red[(0 * FRL + ty) * FCPB + tx] = s0 + s1;
+  red[(1 * FRL + ty) * FCPB + tx] = q0 + q1;
+  __syncthreads();
+  if (ty == 0 && c < f.C) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll 16
+    for (int j = 0; j < FRL; ++j) { s += red[(0 * FRL + j) * FCPB + tx]; ss += red[(1 * FRL + j) * FCPB + tx]; }
+    if (seg) { f.table_out[c] = s; f.table_out[f.ldp + c] = ss; }
+    const float mean = s / f.count;
+    float var = ss / f.count - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float invstd = rsqrtf(var + f.eps);
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    f.mean[c] = mean;                                     // read by later launches only
+    f.invstd[c] = invstd;
+    st_agent(f.scale + c, g * invstd);                    // read by the consumers of this launch
+    st_agent(f.shift + c, b - mean * g * invstd);
+    if (f.rmean) {
+      f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * mean;
+      const float unb = f.count > 1.f ? var * f.count / (f.count - 1.f) : var;
+      f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * unb;
+    }
+  }
+}
+
+// k_bn_apply with up to two BatchNorms finalized by its first workgroups: f1 = the BatchNorm applied to y, f2 = the
+// BatchNorm of the residual (projection shortcut: a.rscale / a.rshift), nblk 0 when absent or already final.
+template <bool FIXED_C>
+__global__ void __launch_bounds__(256) k_bn_apply_fused(ApplyArgs a, FinFwd f1, FinFwd f2, FuseSync s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];    // producers: 2*FRL*FCPB floats; consumers: up to 4 C
+  if ((int)blockIdx.x < s.producers) {
+    const int b = blockIdx.x;
+    if (b < f1.nblk) fin_fwd_body(f1, b, lds); else fin_fwd_body(f2, b - f1.nblk, lds);
+    fuse_publish(s);
+    return;
+  }
+  const unsigned bid = blockIdx.x - s.producers, nblk = gridDim.x - s.producers;
+  const int C = a.C, CH = C >> 3;
+  const bool res_bn = a.res && a.rscale;
+  fuse_wait(s);
+  float* l_sc = lds; float* l_sh = lds + C; float* l_rs = lds + 2 * C; float* l_rh = lds + 3 * C;
+  // BNState keeps scale and shift in consecutive rows: one staging pass (one memory round trip) for both
+  if (f1.nblk) {
+    if (a.shift == a.scale + C) stage_agent(l_sc, a.scale, 2 * C);
+    else { stage_agent(l_sc, a.scale, C); stage_agent(l_sh, a.shift, C); }
+  } else { for (int i = threadIdx.x; i < C; i += 256) { l_sc[i] = a.scale[i]; l_sh[i] = a.shift[i]; } }
+  if (res_bn) {
+    if (f2.nblk) {
+      if (a.rshift == a.rscale + C) stage_agent(l_rs, a.rscale, 2 * C);
+      else { stage_agent(l_rs, a.rscale, C); stage_agent(l_rh, a.rshift, C); }
+    } else { for (int i = threadIdx.x; i < C; i += 256) { l_rs[i] = a.rscale[i]; l_rh[i] = a.rshift[i]; } }
+  }
+  __syncthreads();
+  const long long total = a.npix * CH;
+  float sc[8], sh[8], rs[8], rh[8];
+  if (FIXED_C) {
+    const int cc = (int)((bid * 256u + threadIdx.x) % CH) * 8;
+    load8f(l_sc + cc, sc);
+    load8f(l_sh + cc, sh);
+    if (res_bn) { load8f(l_rs + cc, rs); load8f(l_rh + cc, rh); }
+  }
+  const unsigned i0 = bid * 256u + threadIdx.x;
+  const long long dpix = FIXED_C ? (long long)nblk * 256 / CH : 0;
+  long long pix_f = i0 / (unsigned)CH;
+  const int cc_f = (int)(i0 % (unsigned)CH) * 8;
+  for (long long i = i0; FIXED_C ? pix_f < a.npix : i < total; i += (long long)nblk * 256, pix_f += dpix) {
+    const long long pix = FIXED_C ? pix_f : i / CH;
+    const int cc = FIXED_C ? cc_f : (int)(i - pix * CH) * 8;
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.y + pix * a.ldy + cc), f);
+    if (!FIXED_C) { load8f(l_sc + cc, sc); load8f(l_sh + cc, sh); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = f[k] * sc[k] + sh[k];
+    if (a.res) {
+      float r[8];
+      unpack8(*reinterpret_cast<const u32x4*>(a.res + pix * a.ldr + cc), r);
+      if (a.rscale) {
+        if (!FIXED_C) { load8f(l_rs + cc, rs); load8f(l_rh + cc, rh); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = r[k] * rs[k] + rh[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] += r[k];
+    }
+    if (a.relu) {
+      if (a.relu_mask) {
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m |= (f[k] > 0.f ? 1u : 0u) << k;
+        a.relu_mask[pix * CH + (cc >> 3)] = (unsigned char)m;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
+    }
+    const u32x4 zb = pack8(f);
+    *reinterpret_cast<u32x4*>(a.z + pix * a.ldz + cc) = zb;
+    if (a.z8) {
+      float r[8];
+      unpack8(zb, r);
+      uint2 o;
+      o.x = pack_e4m3x4(r[0], r[1], r[2], r[3]);
+      o.y = pack_e4m3x4(r[4], r[5], r[6], r[7]);
+      *reinterpret_cast<uint2*>(a.z8 + pix * a.ldz8 + cc) = o;
+    }
+  }
+}
+
+// Backward finalize (the arithmetic of k_bn_bwd_finalize) on FCPB channels per 256-thread workgroup.
+struct FinBwd {
+  const float* part; int rows, C; float count;
+  const float* gamma; const float* invstd;
+  float* dgamma; float* dbeta; float* k1; float* k2; float* k3;
+  int nblk;
+};
+
+__device__ __forceinline__ void fin_bwd_body(const FinBwd& f, int blk, float* red) {
+  const int tx = threadIdx.x % FCPB, ty = threadIdx.x / FCPB;
+  const int c = blk * FCPB + tx;
+  float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+  if (c < f.C) {
+    const size_t rs = (size_t)2 * f.C;
+    int r = ty;
+#pragma unroll 2
+    for (; r + FRL < f.rows; r += 2 * FRL) {
+      s0 += f.part[(size_t)r * rs + c];
+      q0 += f.part[(size_t)r * rs + f.C + c];
+      s1 += f.part[(size_t)(r + FRL) * rs + c];
+      q1 += f.part[(size_t)(r + FRL) * rs + f.C + c];
+    }
+    for (; r < f.rows; r += FRL) {
+      s0 += f.part[(size_t)r * rs + c];
+      q0 += f.part[(size_t)r * rs + f.C + c];
+    }
+  }
+  red[(0 * FRL + ty) * FCPB + tx] = s0 + s1;
+  red[(1 * FRL + ty) * FCPB + tx] = q0 + q1;
+  __syncthreads();
+  if (ty == 0 && c < f.C) {
+    float s = 0.f, sx = 0.f;
+#pragma unroll 16
+    for (int j = 0; j < FRL; ++j) { s += red[(0 * FRL + j) * FCPB + tx]; sx += red[(1 * FRL + j) * FCPB + tx]; }
+    if (f.dgamma) f.dgamma[c] = sx;
+    if (f.dbeta) f.dbeta[c] = s;
+    const float g = f.gamma ? f.gamma[c] : 1.f;
+    const float a1 = g * f.invstd[c];
+    st_agent(f.k1 + c, a1);
+    st_agent(f.k2 + c, a1 * s / f.count);
+    st_agent(f.k3 + c, a1 * sx / f.count);
+  }
+}
+
+// coefficient vectors of the backward apply from LDS copies of k1/k2/k3 (mean / invstd come from earlier launches)
+__device__ __forceinline__ void bwd_coeffs_lds(const float* mean, const float* invstd, const float* l_k1, const float* l_k2,
+                                               const float* l_k3, int c8, float* k1, float* ka, float* kb) {
+  float mu[8], is[8], k2[8], k3[8];
+  load8f(mean + c8, mu); load8f(invstd + c8, is);
+  load8f(l_k1 + c8, k1); load8f(l_k2 + c8, k2); load8f(l_k3 + c8, k3);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float t = is[k] * k3[k];
+    ka[k] = -t;
+    kb[k] = mu[k] * t - k2[k];
+  }
+}
+
+// k_bn_bwd_apply (no pooled gather) with its finalize in the first workgroups.
+template <bool FIXED_C>
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_fused(BwdArgs a, FinBwd f1, FuseSync s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x < s.producers) {
+    fin_bwd_body(f1, blockIdx.x, lds);
+    fuse_publish(s);
+    return;
+  }
+  const unsigned bid = blockIdx.x - s.producers, nblk = gridDim.x - s.producers;
+  const int C = a.C, CH = C >> 3;
+  fuse_wait(s);
+  float* l_k1 = lds; float* l_k2 = lds + C; float* l_k3 = lds + 2 * C;
+  if (a.k2 == a.k1 + C && a.k3 == a.k1 + 2 * C) stage_agent(l_k1, a.k1, 3 * C);     // consecutive rows of one scratch buffer
+  else { stage_agent(l_k1, a.k1, C); stage_agent(l_k2, a.k2, C); stage_agent(l_k3, a.k3, C); }
+  __syncthreads();
+  const long long total = a.npix * CH;
+  float k1[8], ka[8], kb[8], sc[8], sh[8];
+  if (FIXED_C) {
+    const int c8 = (int)((bid * 256u + threadIdx.x) % CH) * 8;
+    bwd_coeffs_lds(a.mean, a.invstd, l_k1, l_k2, l_k3, c8, k1, ka, kb);
+    if (a.mask_mode == 2) { load8f(a.scale + c8, sc); load8f(a.shift + c8, sh); }
+  }
+  const unsigned i0 = bid * 256u + threadIdx.x;
+  const long long dpix = FIXED_C ? (long long)nblk * 256 / CH : 0;
+  long long pix_f = i0 / (unsigned)CH;
+  const int cc_f = (int)(i0 % (unsigned)CH) * 8;
+  for (long long i = i0; FIXED_C ? pix_f < a.npix : i < total; i += (long long)nblk * 256, pix_f += dpix) {
+    const long long p = FIXED_C ? pix_f : i / CH;
+    const int c8 = FIXED_C ? cc_f : (int)(i - p * CH) * 8;
+    float yv[8], g[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8), yv);
+    if (FIXED_C) masked_grad(a, p, c8, yv, g, sc, sh);
+    else masked_grad(a, p, c8, yv, g);
+    if (a.dres) *reinterpret_cast<u32x4*>(a.dres + p * a.lddres + c8) = pack8(g);
+    if (!FIXED_C) bwd_coeffs_lds(a.mean, a.invstd, l_k1, l_k2, l_k3, c8, k1, ka, kb);
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = k1[k] * g[k] + (ka[k] * yv[k] + kb[k]);
+    if (a.accumulate) {
+      float old[8];
+      unpack8(*reinterpret_cast<const u32x4*>(a.dy + p * a.lddy + c8), old);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += old[k];
+    }
+    *reinterpret_cast<u32x4*>(a.dy + p * a.lddy + c8) = pack8(o);
+  }
+}
+
+// Dual form (projection blocks): both finalizes in the first workgroups, then k_bn_bwd_apply_dual's loop.
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_dual_fused(BwdArgs a, FinBwd f1, FinBwd f2, FuseSync s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x < s.producers) {
+    const int b = blockIdx.x;
+    if (b < f1.nblk) fin_bwd_body(f1, b, lds); else fin_bwd_body(f2, b - f1.nblk, lds);
+    fuse_publish(s);
+    return;
+  }
+  const unsigned bid = blockIdx.x - s.producers, nblk = gridDim.x - s.producers;
+  const int C = a.C, CH = C >> 3;
+  fuse_wait(s);
+  stage_agent(lds, a.k1, 6 * C);                       // k6: [k1, k2, k3, k1b, k2b, k3b] rows of one scratch buffer
+  __syncthreads();
+  const int c8 = (int)((bid * 256u + threadIdx.x) % CH) * 8;
+  float k1[8], ka[8], kb[8], k1b[8], ka2[8], kb2[8];
+  bwd_coeffs_lds(a.mean, a.invstd, lds, lds + C, lds + 2 * C, c8, k1, ka, kb);
+  bwd_coeffs_lds(a.mean2, a.invstd2, lds + 3 * C, lds + 4 * C, lds + 5 * C, c8, k1b, ka2, kb2);
+  const unsigned i0 = bid * 256u + threadIdx.x;
+  const long long dpix = (long long)nblk * 256 / CH;
+  for (long long p = i0 / (unsigned)CH; p < a.npix; p += dpix) {
+    float yv[8], y2v[8], g[8], o[8], o2[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.y + p * a.ldy + c8), yv);
+    unpack8(*reinterpret_cast<const u32x4*>(a.y2 + p * a.ldy2 + c8), y2v);
+    masked_grad(a, p, c8, yv, g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o[k] = k1[k] * g[k] + (ka[k] * yv[k] + kb[k]);
+      o2[k] = k1b[k] * g[k] + (ka2[k] * y2v[k] + kb2[k]);
+    }
+    *reinterpret_cast<u32x4*>(a.dy + p * a.lddy + c8) = pack8(o);
+    *reinterpret_cast<u32x4*>(a.dy2 + p * a.lddy2 + c8) = pack8(o2);
+  }
+}
+
 // ---- pooled form on aligned 2x2 patches (even H and W: the stems) ------------------------------------------------
 // The per-pixel gather above re-reads every pool window for each of the up-to-nine pixels under it and pays two integer
 // divisions per pixel; it is latency-bound (the stem's pair ran no faster than max-pool backward + plain BN backward).
@@ -1288,6 +1652,148 @@ extern "C" int yv1_bn_apply_q8(const void* y, int ldy, void* z, int ldz, const v
   if (!z8) return YV1_ERR_BAD_ARG;
   return bn_apply_launch(y, ldy, z, ldz, residual, ldr, scale, shift, res_scale, res_shift, npix, C, relu, relu_mask, z8,
                          ldz8, stream);
+}
+
+// ---- finalize + apply in one launch (see "finalize fused into the consuming launch" above) ----------------------------
+// `sync`: two zero-initialised unsigned words owned by this launch until it completes (the kernel leaves them zero again);
+// `fault`: one word the host checks -- a consumer that gave up waiting sets it (never observed).
+static FinFwd make_fin_fwd(const float* partials, int rows, int C, int ld, float count, const float* gamma, const float* beta,
+                           float eps, float momentum, float* rmean, float* rvar, float* mean, float* invstd, float* scale,
+                           float* shift) {
+  FinFwd f;
+  f.part = partials; f.rows = rows; f.C = C; f.ldp = ld; f.count = count; f.gamma = gamma; f.beta = beta; f.eps = eps;
+  f.momentum = momentum; f.rmean = rmean; f.rvar = rvar; f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
+  f.nblk = partials ? (C + FCPB - 1) / FCPB : 0;
+  return f;
+}
+
+extern "C" int yv1_bn_finalize_apply(const float* partials, int rows, int ld_partials, float count, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                     float* mean, float* invstd, float* scale, float* shift, const float* r_partials,
+                                     int r_rows, int r_ld_partials, const float* r_gamma, const float* r_beta,
+                                     float* r_running_mean, float* r_running_var, float* r_mean, float* r_invstd,
+                                     float* r_scale, float* r_shift, const void* y, int ldy, void* z, int ldz,
+                                     const void* residual, int ldr, long long npix, int C, int relu, void* relu_mask,
+                                     void* z8, int ldz8, unsigned* sync, unsigned* fault, hipStream_t stream) {
+  if (!partials || rows <= 0 || !mean || !invstd || !scale || !shift || !y || !z || npix <= 0 || C <= 0 || !sync || !fault)
+    return YV1_ERR_BAD_ARG;
+  if (r_partials && (r_rows <= 0 || !r_mean || !r_invstd || !r_scale || !r_shift || !residual)) return YV1_ERR_BAD_ARG;
+  if (C % 8 || C > 4096 || ldy % 8 || ldz % 8 || (residual && ldr % 8) || (z8 && ldz8 % 8)) return YV1_ERR_UNSUPPORTED;
+  ApplyArgs a;
+  a.y = (const bf16_t*)y; a.ldy = ldy; a.z = (bf16_t*)z; a.ldz = ldz; a.res = (const bf16_t*)residual; a.ldr = ldr;
+  a.scale = scale; a.shift = shift; a.rscale = r_scale; a.rshift = r_shift; a.npix = npix; a.C = C; a.relu = relu;
+  a.relu_mask = (unsigned char*)relu_mask; a.z8 = (unsigned char*)z8; a.ldz8 = ldz8;
+  const FinFwd f1 = make_fin_fwd(partials, rows, C, ld_partials, count, gamma, beta, eps, momentum, running_mean, running_var,
+                                 mean, invstd, scale, shift);
+  const FinFwd f2 = make_fin_fwd(r_partials, r_rows, C, r_ld_partials, count, r_gamma, r_beta, eps, momentum, r_running_mean,
+                                 r_running_var, r_mean, r_invstd, r_scale, r_shift);
+  FuseSync s; s.ctr = sync; s.fault = fault; s.producers = f1.nblk + f2.nblk;
+  bool fixed;
+  const int blocks = fixed_chunk_grid(npix * (C / 8), C / 8, &fixed);
+  const size_t lds = sizeof(float) * (size_t)((4 * C) > 2 * FRL * FCPB ? 4 * C : 2 * FRL * FCPB);
+  if (fixed) hipLaunchKernelGGL(k_bn_apply_fused<true>, dim3(s.producers + blocks), dim3(256), lds, stream, a, f1, f2, s);
+  else hipLaunchKernelGGL(k_bn_apply_fused<false>, dim3(s.producers + blocks), dim3(256), lds, stream, a, f1, f2, s);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+// DenseNet form of yv1_bn_finalize_apply (see yv1_bn_finalize_merged): `table` is the block's one-row [2][ld] table of
+// channel sums; its columns [seg_c0, seg_c0 + seg_c) are still seg_part [seg_rows][2][seg_c] (seg_part may be NULL: plain
+// table); the BatchNorm acts on the first C channels of y (a window of the block buffer), no residual.
+extern "C" int yv1_bn_finalize_merged_apply(float* table, int C, int ld, float count, const float* gamma, const float* beta,
+                                            float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                            float* invstd, float* scale, float* shift, const float* seg_part, int seg_rows,
+                                            int seg_c0, int seg_c, const void* y, int ldy, void* z, int ldz, long long npix,
+                                            int relu, unsigned* sync, unsigned* fault, hipStream_t stream) {
+  if (!table || C <= 0 || C > ld || !mean || !invstd || !scale || !shift || !y || !z || npix <= 0 || !sync || !fault)
+    return YV1_ERR_BAD_ARG;
+  if (seg_part && (seg_rows <= 0 || seg_c <= 0 || seg_c0 < 0 || seg_c0 + seg_c > C)) return YV1_ERR_BAD_ARG;
+  if (C % 8 || C > 4096 || ldy % 8 || ldz % 8) return YV1_ERR_UNSUPPORTED;
+  ApplyArgs a;
+  a.y = (const bf16_t*)y; a.ldy = ldy; a.z = (bf16_t*)z; a.ldz = ldz; a.res = nullptr; a.ldr = 0;
+  a.scale = scale; a.shift = shift; a.rscale = nullptr; a.rshift = nullptr; a.npix = npix; a.C = C; a.relu = relu;
+  a.relu_mask = nullptr; a.z8 = nullptr; a.ldz8 = 0;
+  FinFwd f1 = make_fin_fwd(table, 1, C, ld, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale,
+                           shift);
+  f1.seg_part = seg_part; f1.seg_rows = seg_rows; f1.seg_c0 = seg_c0; f1.seg_c = seg_c; f1.table_out = table;
+  const FinFwd f2 = make_fin_fwd(nullptr, 0, C, 0, count, nullptr, nullptr, eps, momentum, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr);
+  FuseSync s; s.ctr = sync; s.fault = fault; s.producers = f1.nblk;
+  bool fixed;
+  const int blocks = fixed_chunk_grid(npix * (C / 8), C / 8, &fixed);
+  const size_t lds = sizeof(float) * (size_t)((4 * C) > 2 * FRL * FCPB ? 4 * C : 2 * FRL * FCPB);
+  if (fixed) hipLaunchKernelGGL(k_bn_apply_fused<true>, dim3(s.producers + blocks), dim3(256), lds, stream, a, f1, f2, s);
+  else hipLaunchKernelGGL(k_bn_apply_fused<false>, dim3(s.producers + blocks), dim3(256), lds, stream, a, f1, f2, s);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+static FinBwd make_fin_bwd(const float* partials, int rows, int C, float count, const float* gamma, const float* invstd,
+                           float* dgamma, float* dbeta, float* k1, float* k2, float* k3) {
+  FinBwd f;
+  f.part = partials; f.rows = rows; f.C = C; f.count = count; f.gamma = gamma; f.invstd = invstd; f.dgamma = dgamma;
+  f.dbeta = dbeta; f.k1 = k1; f.k2 = k2; f.k3 = k3; f.nblk = partials ? (C + FCPB - 1) / FCPB : 0;
+  return f;
+}
+
+// yv1_bn_bwd_finalize + yv1_bn_bwd_apply in one launch (partials from yv1_bn_bwd_reduce); k1/k2/k3 are scratch [C] each.
+extern "C" int yv1_bn_bwd_finalize_apply(const float* partials, int rows, float count, const float* gamma, float* dgamma,
+                                         float* dbeta, float* k1, float* k2, float* k3, const void* dz, int lddz,
+                                         const void* z, int ldz, const void* y, int ldy, const float* mean,
+                                         const float* invstd, const float* scale, const float* shift, long long npix, int C,
+                                         int mask_mode, void* dy, int lddy, void* dres, int lddres, int accumulate,
+                                         unsigned* sync, unsigned* fault, hipStream_t stream) {
+  if (!partials || rows <= 0 || !dz || !y || !mean || !invstd || !k1 || !k2 || !k3 || !dy || npix <= 0 || !sync || !fault)
+    return YV1_ERR_BAD_ARG;
+  if (((mask_mode == 1 || mask_mode == 3) && !z) || (mask_mode == 2 && (!scale || !shift))) return YV1_ERR_BAD_ARG;
+  if (C % 8 || C > 4096 || lddz % 8 || ldy % 8 || lddy % 8 || (z && mask_mode == 1 && ldz % 8) || (dres && lddres % 8))
+    return YV1_ERR_UNSUPPORTED;
+  BwdArgs a = {};
+  a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
+  a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.npix = npix; a.C = C; a.mask_mode = mask_mode;
+  a.k1 = k1; a.k2 = k2; a.k3 = k3; a.dy = (bf16_t*)dy; a.lddy = lddy; a.dres = (bf16_t*)dres; a.lddres = lddres;
+  a.accumulate = accumulate;
+  const FinBwd f1 = make_fin_bwd(partials, rows, C, count, gamma, invstd, dgamma, dbeta, k1, k2, k3);
+  FuseSync s; s.ctr = sync; s.fault = fault; s.producers = f1.nblk;
+  bool fixed;
+  const int blocks = fixed_chunk_grid(npix * (C / 8), C / 8, &fixed);
+  const size_t lds = sizeof(float) * (size_t)((3 * C) > 2 * FRL * FCPB ? 3 * C : 2 * FRL * FCPB);
+  if (fixed) hipLaunchKernelGGL(k_bn_bwd_apply_fused<true>, dim3(s.producers + blocks), dim3(256), lds, stream, a, f1, s);
+  else hipLaunchKernelGGL(k_bn_bwd_apply_fused<false>, dim3(s.producers + blocks), dim3(256), lds, stream, a, f1, s);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+// Dual form: both finalizes (partials / partials2 from yv1_bn_bwd_reduce_dual) + yv1_bn_bwd_apply_dual in one launch.
+extern "C" int yv1_bn_bwd_finalize_apply_dual(const float* partials, const float* partials2, int rows, float count,
+                                              const float* gamma, const float* gamma2, float* dgamma, float* dbeta,
+                                              float* dgamma2, float* dbeta2, float* k6 /* [6][C] scratch */, const void* dz,
+                                              int lddz, const void* z, int ldz, const void* y, int ldy, const float* mean,
+                                              const float* invstd, void* dy, int lddy, const void* y2, int ldy2,
+                                              const float* mean2, const float* invstd2, void* dy2, int lddy2, long long npix,
+                                              int C, int mask_mode, unsigned* sync, unsigned* fault, hipStream_t stream) {
+  if (!partials || !partials2 || rows <= 0 || !k6 || !dz || !y || !y2 || !mean || !invstd || !mean2 || !invstd2 || !dy || !dy2 ||
+      npix <= 0 || !sync || !fault)
+    return YV1_ERR_BAD_ARG;
+  if (mask_mode == 2 || ((mask_mode == 1 || mask_mode == 3) && !z)) return YV1_ERR_BAD_ARG;
+  if (C % 8 || C > 2048 || lddz % 8 || ldy % 8 || ldy2 % 8 || lddy % 8 || lddy2 % 8 || (z && mask_mode == 1 && ldz % 8))
+    return YV1_ERR_UNSUPPORTED;
+  BwdArgs a = {};
+  a.dz = (const bf16_t*)dz; a.lddz = lddz; a.z = (const bf16_t*)z; a.ldz = ldz; a.y = (const bf16_t*)y; a.ldy = ldy;
+  a.mean = mean; a.invstd = invstd; a.npix = npix; a.C = C; a.mask_mode = mask_mode;
+  a.k1 = k6; a.k2 = k6 + C; a.k3 = k6 + 2 * C; a.dy = (bf16_t*)dy; a.lddy = lddy;
+  a.y2 = (const bf16_t*)y2; a.ldy2 = ldy2; a.mean2 = mean2; a.invstd2 = invstd2; a.k1b = k6 + 3 * C; a.k2b = k6 + 4 * C;
+  a.k3b = k6 + 5 * C; a.dy2 = (bf16_t*)dy2; a.lddy2 = lddy2;
+  const FinBwd f1 = make_fin_bwd(partials, rows, C, count, gamma, invstd, dgamma, dbeta, k6, k6 + C, k6 + 2 * C);
+  const FinBwd f2 = make_fin_bwd(partials2, rows, C, count, gamma2, invstd2, dgamma2, dbeta2, k6 + 3 * C, k6 + 4 * C, k6 + 5 * C);
+  FuseSync s; s.ctr = sync; s.fault = fault; s.producers = f1.nblk + f2.nblk;
+  bool fixed;
+  const int blocks = fixed_chunk_grid(npix * (C / 8), C / 8, &fixed);
+  if (!fixed) return YV1_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(float) * (size_t)((6 * C) > 2 * FRL * FCPB ? 6 * C : 2 * FRL * FCPB);
+  hipLaunchKernelGGL(k_bn_bwd_apply_dual_fused, dim3(s.producers + blocks), dim3(256), lds, stream, a, f1, f2, s);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
 }
 
 // pixels per workgroup of the column-parallel reductions: aim for ~2048 workgroups (8 per CU) so small

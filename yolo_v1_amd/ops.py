@@ -522,6 +522,101 @@ def bn_finalize(stats, count, bn, C=None, training=True, seg=None):
     return st
 
 
+# ---- finalize fused into the consuming launch (csrc/elementwise.hip, "finalize fused into the consuming launch")
+import os as _os
+# Measured (tools/bench_bn_fused.py, profiles/r03_bn_fused_table.txt): the fused form is SLOWER on every shape -- +14 us on
+# the small tensors, +50 us at C = 2048 -- and the step loses 13 % with it.  A dependent launch inside a captured graph
+# costs ~1-2 us and a finalize kernel ~3 us (the 5-7 us / 4.5 us gap figures of round 2 were rocprofv3's), while
+# publishing through memory and polling across the XCDs costs 13-18 us per hand-off (the guide's "barrier-counter" row
+# says 7-26).  Off by default; kept as the record of the experiment, bit-identical to the launch pairs (tests).
+BN_FUSED = _os.environ.get("YV1_BN_FUSED", "0") == "1"
+_SYNC = {}
+_SYNC_SLOTS = 4096
+
+
+def _sync_slot(device):
+    """(sync pointer, fault pointer): a self-resetting counter pair for ONE fused launch and the device's fault word.
+    Slots are handed out round-robin from one zero-initialised buffer per device; a slot comes round again 4096 fused
+    launches later, long after the launch that used it has finished (the kernel leaves the pair zeroed)."""
+    key = torch.device(device).index
+    ent = _SYNC.get(key)
+    if ent is None:
+        ent = [torch.zeros((_SYNC_SLOTS + 1) * 2, dtype=torch.int32, device=device), 0]
+        _SYNC[key] = ent
+    buf = ent[0]
+    ent[1] = ent[1] % _SYNC_SLOTS + 1                     # slots 1 .. 4096; words 0/1 of the buffer: fault word + spare
+    base = buf.data_ptr()
+    return _lib.c_p(base + 8 * ent[1]), _lib.c_p(base)
+
+
+def fused_sync_fault(device=None):
+    """True when a consumer workgroup of a fused finalize+apply launch ever gave up waiting for its producers (never
+    observed; the spin's exit condition).  Host sync.  Tests and bench.py assert it is False."""
+    out = False
+    for key, (buf, _) in _SYNC.items():
+        if device is None or torch.device(device).index == key:
+            out = out or bool(int(buf[0].item()) != 0)
+    return out
+
+
+def bn_finalize_apply(stats, count, bn, y, z, relu=True, residual=None, res_stats=None, res_bn=None, res_state=None,
+                      want_mask=False, z8=None, C=None):
+    """bn_finalize + bn_apply in ONE launch (training mode): ``stats`` are the partial rows of the convolution that produced
+    ``y``; with ``res_stats`` / ``res_bn`` the residual is a raw projection-shortcut output whose BatchNorm is finalized by
+    the same launch (else ``res_state``: an already finalized BNState, or None for a plain residual).
+    Returns (BNState of bn, ReluMask or None, BNState of res_bn or None)."""
+    dev = y.t.device
+    rows, _, ld = stats.shape
+    C = C or bn.num_features
+    st = BNState(C, dev)
+    st.count = count
+    part, rows = _shrink_partials(stats, rows, 2 * ld, dev)
+    rst, rpart, rrows, rld = res_state, None, 0, 0
+    if res_stats is not None:
+        rrows, _, rld = res_stats.shape
+        rst = BNState(C, dev)
+        rst.count = count
+        rpart, rrows = _shrink_partials(res_stats, rrows, 2 * rld, dev)
+    mask = ReluMask(y.npix, y.C, dev) if (want_mask and relu) else None
+    sync, fault = _sync_slot(dev)
+    check(lib().yv1_bn_finalize_apply(
+        ptr(part), rows, ld, float(count), ptr(bn.weight), ptr(bn.bias), BN_EPS, BN_MOMENTUM, ptr(bn.running_mean),
+        ptr(bn.running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
+        ptr(rpart), rrows, rld, ptr(res_bn.weight) if rpart is not None else None, ptr(res_bn.bias) if rpart is not None else None,
+        ptr(res_bn.running_mean) if rpart is not None else None, ptr(res_bn.running_var) if rpart is not None else None,
+        ptr(rst.mean) if rpart is not None else None, ptr(rst.invstd) if rpart is not None else None,
+        ptr(rst.scale) if rst is not None else None, ptr(rst.shift) if rst is not None else None,
+        y.p, y.ld, z.p, z.ld, residual.p if residual is not None else None, residual.ld if residual is not None else 0,
+        y.npix, y.C, 1 if relu else 0, mask.p if mask is not None else None, z8.p if z8 is not None else None,
+        z8.ld if z8 is not None else 0, sync, fault, stream_ptr(dev)), "yv1_bn_finalize_apply")
+    return st, mask, (rst if res_stats is not None else None)
+
+
+def bn_finalize_merged_apply(table, count, bn, C, x, z, seg=None, relu=True):
+    """DenseNet: bn_finalize(table, ..., seg=seg) + bn_apply(x, st, z) in one launch.  ``table`` [1][2][ld]."""
+    dev = x.t.device
+    rows, _, ld = table.shape
+    if rows != 1:
+        raise ValueError("bn_finalize_merged_apply needs the one-row table")
+    st = BNState(C, dev)
+    st.count = count
+    part = prow = None
+    c0 = cseg = 0
+    if seg is not None:
+        part, c0 = seg
+        prow, _, cseg = part.shape
+        if c0 + cseg > C:
+            raise ValueError("bn_finalize_merged_apply: the merged segment must lie inside the finalized channels")
+        part, prow = _shrink_partials(part, prow, 2 * cseg, dev)
+    sync, fault = _sync_slot(dev)
+    check(lib().yv1_bn_finalize_merged_apply(ptr(table), C, ld, float(count), ptr(bn.weight), ptr(bn.bias), BN_EPS, BN_MOMENTUM,
+                                             ptr(bn.running_mean), ptr(bn.running_var), ptr(st.mean), ptr(st.invstd),
+                                             ptr(st.scale), ptr(st.shift), ptr(part), prow or 0, c0, cseg, x.p, x.ld, z.p, z.ld,
+                                             x.npix, 1 if relu else 0, sync, fault, stream_ptr(dev)),
+          "yv1_bn_finalize_merged_apply")
+    return st
+
+
 def bn_eval_state(bn):
     dev = bn.weight.device
     st = BNState(bn.num_features, dev)
@@ -602,6 +697,14 @@ def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=Fals
     dgam, dbet = gb[0], gb[1]
     if _ARENA[0] is not None and bn is not None and bn.weight.numel() == C:
         dgam, dbet = _grad_buf(bn.weight, (C,)), _grad_buf(bn.bias, (C,))
+    if BN_FUSED and pool_idx is None:
+        sync, fault = _sync_slot(dev)
+        check(L.yv1_bn_bwd_finalize_apply(ptr(part), rows, float(y.npix), ptr(bn.weight) if bn is not None else None, ptr(dgam),
+                                          ptr(dbet), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), dz.p, dz.ld, zp, zld, y.p, y.ld,
+                                          ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), y.npix, C, mask_mode,
+                                          dy.p, dy.ld, dres.p if dres is not None else None, dres.ld if dres is not None else 0,
+                                          1 if accumulate else 0, sync, fault, s), "yv1_bn_bwd_finalize_apply")
+        return dgam, dbet
     check(L.yv1_bn_bwd_finalize(ptr(part), rows, C, float(y.npix), ptr(bn.weight) if bn is not None else None,
                                 ptr(st.invstd), ptr(dgam), ptr(dbet), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), s),
           "yv1_bn_bwd_finalize")
@@ -631,6 +734,22 @@ def bn_backward_dual(dz, mask, a, b):
     pa, pb = _f32(rows * 2 * C, dev), _f32(rows * 2 * C, dev)
     check(L.yv1_bn_bwd_reduce_dual(dz.p, dz.ld, mask.p, mask.ld, ya.p, ya.ld, ptr(sta.mean), ptr(sta.invstd), yb.p, yb.ld,
                                    ptr(stb.mean), ptr(stb.invstd), ya.npix, C, 3, ptr(pa), ptr(pb), s), "yv1_bn_bwd_reduce_dual")
+    if BN_FUSED and rows <= 2048:
+        k6 = torch.empty((6, C), dtype=torch.float32, device=dev)
+        gr = []
+        for bn in (bna, bnb):
+            if _ARENA[0] is not None:
+                gr.append((_grad_buf(bn.weight, (C,)), _grad_buf(bn.bias, (C,))))
+            else:
+                g2 = torch.empty((2, C), dtype=torch.float32, device=dev)
+                gr.append((g2[0], g2[1]))
+        sync, fault = _sync_slot(dev)
+        check(L.yv1_bn_bwd_finalize_apply_dual(ptr(pa), ptr(pb), rows, float(ya.npix), ptr(bna.weight), ptr(bnb.weight),
+                                               ptr(gr[0][0]), ptr(gr[0][1]), ptr(gr[1][0]), ptr(gr[1][1]), ptr(k6), dz.p, dz.ld,
+                                               mask.p, mask.ld, ya.p, ya.ld, ptr(sta.mean), ptr(sta.invstd), dya.p, dya.ld,
+                                               yb.p, yb.ld, ptr(stb.mean), ptr(stb.invstd), dyb.p, dyb.ld, ya.npix, C, 3,
+                                               sync, fault, s), "yv1_bn_bwd_finalize_apply_dual")
+        return gr[0], gr[1]
     out, ks = [], []
     for part, st, bn in ((pa, sta, bna), (pb, stb, bnb)):
         part, r = _shrink_partials(part, rows, 2 * C, dev)
