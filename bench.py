@@ -208,6 +208,13 @@ def other_training_config(backbone, S, batch, device, fp8_forward=False, steps=8
            "dtype": "fp8-e4m3 forward GEMMs, bf16 backward" if fp8_forward else "bf16",
            "value": round(batch / ms * 1e3, 1), "unit": "images/sec", "ms_per_step": round(ms, 3), "steps": steps,
            "achieved_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 5)}
+    if not fp8_forward:                          # PMC traffic of this configuration, when committed for these kernel sources
+        traffic, prov = measured_traffic(backbone, S, batch)
+        out["traffic"] = traffic
+        out["hbm_GBps"] = round(traffic / (ms * 1e-3) / 1e9, 1) if traffic else None
+        out["hbm_frac"] = round(traffic / (ms * 1e-3) / 8e12, 4) if traffic else None
+        if not traffic:
+            out["traffic_note"] = prov.get("note")
     graphed.close()            # the hipGraphExec, its private pool (all saved activations) and its streams go back NOW
     del graphed, net, opt, loss_layer
     torch.cuda.empty_cache()

@@ -93,10 +93,10 @@ int yv1_convert_cxcywh_to_xyxy(const float* in, int n, int S, float* out, yv1_st
 
 /* ---- convolution: nn.Conv2d behind OriginResNet.py:21-29,:121,:159-163; OriginDenseNet.py:24-29,:52-53,:77,:101 */
 /* y = conv(x, w), square kernel k; w bf16 [Cout][k*k][Cin] (Cin % 32 == 0, Cout % 32 == 0).
- * stats (nullable): BatchNorm partials [yv1_conv2d_stats_rows(M,Cout,Cin,k)][2][Cout], M = N*OH*OW. */
+ * stats (nullable): BatchNorm partials [yv1_conv2d_stats_rows(M,Cout,Cin,k,stride,pad)][2][Cout], M = N*OH*OW. */
 int yv1_conv2d_fwd_nhwc_bf16(const void* x, const void* w, void* y, int N, int IH, int IW, int ldx, int Cin, int Cout,
                              int ldy, int k, int stride, int pad, float* stats, yv1_stream_t stream);
-int yv1_conv2d_stats_rows(int M, int Cout, int Cin, int k);
+int yv1_conv2d_stats_rows(int M, int Cout, int Cin, int k, int stride, int pad);
 /* 7x7/2 pad-3 stem over the packed image: xp [N][H+6][W+6][4] bf16; w bf16 [Cout][7][32] */
 int yv1_conv2d_stem_fwd_bf16(const void* xp, const void* w, void* y, int N, int H, int W, int Cout, int ldy, float* stats,
                              yv1_stream_t stream);

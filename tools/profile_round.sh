@@ -11,6 +11,14 @@ BENCH="python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --host-input 0 --
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --graph 0 > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --graph 0 > $OUT/pmc_write.log 2>&1 || exit 1
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/pmc_traffic.log 2>&1 || exit 1
+# the other BASELINE configurations' traffic (bench.py other_configs reports it beside their img/s)
+for cfg in "--backbone densenet:densenet_S7:densenet S=7 batch 64" "--S 14:resnet_S14:resnet S=14 batch 64"; do
+  flags=${cfg%%:*}; rest=${cfg#*:}; name=${rest%%:*}; wl=${rest#*:}
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$name -- $BENCH $flags --graph 0 > $OUT/pmc_fetch_$name.log 2>&1 || exit 1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$name -- $BENCH $flags --graph 0 > $OUT/pmc_write_$name.log 2>&1 || exit 1
+  python3 tools/pmc_traffic.py $OUT/pmc_fetch_$name $OUT/pmc_write_$name $OUT/${TAG}_${name}_pmc_traffic.json "$wl" >> $OUT/pmc_traffic.log 2>&1 || exit 1
+  rm -rf $OUT/pmc_fetch_$name $OUT/pmc_write_$name
+done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
   --output-format csv -d $OUT/pmc_sq -- $BENCH --graph 0 > $OUT/pmc_sq.log 2>&1 || exit 1
 python3 tools/pmc_sq.py $OUT/pmc_sq > $OUT/${TAG}_pmc_sq_summary.txt 2>&1 || exit 1

@@ -52,7 +52,7 @@ SIGNATURES = {
     "yv1_conv2d_dgrad_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "yv1_conv2d_dgrad_add_masked_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i,
                                                     c_p]),
-    "yv1_conv2d_stats_rows": (c_i, [c_i, c_i, c_i, c_i]),
+    "yv1_conv2d_stats_rows": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "yv1_pack_input_nhwc4": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     # wgrad.hip
     "yv1_conv2d_wgrad_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),

@@ -309,6 +309,7 @@ class ResNet(HipBackbone):
         inline = ops.SideStream(dev, enabled=False)
         nblk = len(rec["blocks"])
         for bi, brec in enumerate(reversed(rec["blocks"])):
+            side.wide = nblk - bi <= self.wgrad_wide_tail
             g = self.block_backward(brec, g, grads, side if nblk - bi > self.wgrad_main_tail else inline)
             if self._phase_boundary is not None and any(brec[0] is b for b in boundary_blks):
                 side.join()

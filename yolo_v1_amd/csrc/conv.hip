@@ -627,6 +627,211 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128
   conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
 }
 
+// ---- 3x3 stride-1 convolutions: the three taps of a filter row share ONE A tile (round 3) -------------------------
+// The ring kernels fetch the A tile of every filter tap from L2 again: nine fetches of (almost) the same pixels per
+// channel block.  These loops are bound by the global -> LDS fill rate, and on the 3x3 layers A is
+// 1/2 (Cout 64-128) to 4/5 (DenseNet's 128 -> 32 growth convolutions) of what they fill.  For stride 1 / pad 1 the taps
+// (r, 0), (r, 1), (r, 2) of pixel m read pixels m-1, m, m+1 of the flattened image (shifted by (r-1) rows): this kernel
+// stages ONE A tile of BM + 2 consecutive pixels per (filter row, channel block) and runs the three taps off it, reading
+// the fragments of tap s at LDS row m + s.  A-fill per MAC drops 3x; the weights (three tap tiles per stage) are as before.
+//   * LDS row j of a stage holds the pixel with linear index m0 - 1 + j shifted by (r-1) image rows; it is zero (zero page)
+//     when that pixel lies above / below the image.  A consumer m reading row m + s gets its horizontal neighbour
+//     x + s - 1 -- unless that neighbour is outside the row (x == 0 with s == 0, x == W-1 with s == 2): those fragments
+//     are zeroed per lane (the LDS row then holds the wrapped-around pixel of the adjacent image row).
+//   * BM + 2 rows = BM/RPP whole DMA passes + one 1-KB piece issued by wave 0 alone; its counted vmcnt waits are one
+//     deeper per stage than the other waves'.
+//   * dgrad of the same geometry is the forward of the flipped filter: `flip` maps loop tap (r, s) to weight tap
+//     (2-r, 2-s) of the transposed copy.
+// One tile per workgroup, k_conv_dma's ring and the shared epilogue.
+template <int BM, int BN, int BK, int WM, int WN, int NST>
+__global__ void __launch_bounds__(256, ((BM + 64 / (BK / 8)) * BK * 2 + 3 * BN * BK * 2) * NST <= 53 * 1024 ? 3 : (((BM + 64 / (BK / 8)) * BK * 2 + 3 * BN * BK * 2) * NST <= 80 * 1024 ? 2 : 1))
+k_conv_h3(ConvArgs a, int flip) {
+  constexpr int NTH = 256;
+  static_assert(WM * WN == 4, "four waves");
+  constexpr int CPR = BK / 8;
+  constexpr int RPP = NTH / CPR;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tiles must be whole passes");
+  constexpr int A_FULL = BM / RPP;                       // whole A passes (all waves)
+  constexpr int XROWS = 64 / CPR;                        // rows of wave 0's extra 1-KB piece (>= 2)
+  constexpr int A_ROWS = BM + XROWS;
+  constexpr int BP1 = BN / RPP, B_PASSES = 3 * BP1;
+  constexpr int LPS = A_FULL + B_PASSES;                 // DMA instructions per stage and wave (wave 0: + 1)
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = A_ROWS * BK * 2, B1_BYTES = BN * BK * 2, STAGE = A_BYTES + 3 * B1_BYTES;
+  static_assert((NST - 1) * (LPS + 1) < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  int mt, nt;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    mt = lin / a.NT;
+    nt = lin - mt * a.NT;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int W = a.IW, H = a.IH;
+
+  const int slot = tid % CPR, rrow = tid / CPR;
+  const int lchunk = swz<BK>(rrow, slot);                // same key in every pass (RPP, BM are multiples of the key period)
+  // centre pixel (linear index) and image row of the LDS rows this lane fills; pass A_FULL = wave 0's extra piece
+  int pcs[A_FULL + 1], ys[A_FULL + 1];
+#pragma unroll
+  for (int i = 0; i <= A_FULL; ++i) {
+    const int j = (i < A_FULL) ? rrow + i * RPP : BM + rrow;
+    const int pc = m0 - 1 + j;
+    pcs[i] = (pc >= 0 && pc < a.M) ? pc : -1;
+    ys[i] = pc >= 0 ? (pc / W) % H : 0;
+  }
+  const int cblocks = a.Cin / BK;
+  const int nk = 3 * cblocks;
+  const int piece_row0 = (wid * 64) / CPR;
+
+  int ld_r = 0, ld_cb = 0;
+  const bf16_t* asrc[A_FULL + 1];
+  int astep[A_FULL + 1];
+  const bf16_t* wsrc[B_PASSES];
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+#define YV1_SET_ROW_H()                                                                                          \
+  {                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i <= A_FULL; ++i) {                                                        \
+      const int yy = ys[i] + ld_r - 1;                                                                           \
+      const bool ok = pcs[i] >= 0 && yy >= 0 && yy < H;                                                          \
+      asrc[i] = ok ? a.X + ((size_t)(pcs[i] + (ld_r - 1) * W) * a.ldx + lchunk * 8) : zsrc;                      \
+      astep[i] = ok ? BK : 0;                                                                                    \
+    }                                                                                                            \
+    const int wr = flip ? 2 - ld_r : ld_r;                                                                       \
+    _Pragma("unroll") for (int b = 0; b < B_PASSES; ++b) {                                                       \
+      const int s_ = b / BP1, bi_ = b - s_ * BP1;                                                                \
+      const int ws = flip ? 2 - s_ : s_;                                                                         \
+      wsrc[b] = a.W + ((size_t)(n0 + rrow + bi_ * RPP) * a.Kw + (wr * 3 + ws) * a.Cin + lchunk * 8);            \
+    }                                                                                                            \
+  }
+#define YV1_ISSUE_H(STG_)                                                                                        \
+  {                                                                                                              \
+    unsigned char* sa_ = smem + (STG_) * STAGE;                                                                  \
+    unsigned char* sb_ = sa_ + A_BYTES;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < A_FULL; ++i) {                                                         \
+      __builtin_amdgcn_global_load_lds((glb_void*)asrc[i], (lds_void*)(sa_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
+      asrc[i] += astep[i];                                                                                       \
+    }                                                                                                            \
+    if (wid == 0) {                                                                                              \
+      __builtin_amdgcn_global_load_lds((glb_void*)asrc[A_FULL], (lds_void*)(sa_ + BM * (BK * 2)), 16, 0, 0);    \
+      asrc[A_FULL] += astep[A_FULL];                                                                             \
+    }                                                                                                            \
+    _Pragma("unroll") for (int b = 0; b < B_PASSES; ++b) {                                                       \
+      const int s_ = b / BP1, bi_ = b - s_ * BP1;                                                                \
+      __builtin_amdgcn_global_load_lds((glb_void*)wsrc[b],                                                       \
+                                       (lds_void*)(sb_ + s_ * B1_BYTES + (piece_row0 + bi_ * RPP) * (BK * 2)), 16, 0, 0); \
+      wsrc[b] += BK;                                                                                             \
+    }                                                                                                            \
+    if (++ld_cb == cblocks) {                                                                                    \
+      ld_cb = 0;                                                                                                 \
+      ++ld_r;                                                                                                    \
+      if (ld_r < 3) YV1_SET_ROW_H();                                                                             \
+    }                                                                                                            \
+  }
+// counted wait: leave the DMA pieces of `YOUNGER_` whole stages in flight (wave 0 issues one more piece per stage)
+#define YV1_WAIT_H(YOUNGER_)                                                                                     \
+  {                                                                                                              \
+    if (wid == 0) wait_vmcnt<(YOUNGER_) * (LPS + 1)>(); else wait_vmcnt<(YOUNGER_) * LPS>();                     \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  YV1_SET_ROW_H();
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nk) YV1_ISSUE_H(p);
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  constexpr int KS = BK / 16;
+  int fa_off[TM][3], fb_off[TN];
+  bool mleft[TM], mright[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mrow = wm * (BM / WM) + i * 32 + l31;
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      const int row = mrow + s_;
+      fa_off[i][s_] = row * (BK * 2) + swz<BK>(row, lh) * 16;
+    }
+    const int x = (m0 + mrow) % W;
+    mleft[i] = x == 0;
+    mright[i] = x == W - 1;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * (BN / WN) + j * 32 + l31;
+    fb_off[j] = A_BYTES + row * (BK * 2) + swz<BK>(row, lh) * 16;
+  }
+#define YV1_MFMA_BLOCK_H(BASE_)                                                                                  \
+  _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
+      bf16x8 fa[TM], fb[TN];                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>((BASE_) + (fa_off[i][s_] ^ (ks << 5))); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>((BASE_) + s_ * B1_BYTES + (fb_off[j] ^ (ks << 5))); \
+      if (s_ != 1) {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                         \
+          const bool kill = s_ == 0 ? mleft[i] : mright[i];                                                      \
+          u32x4 v = __builtin_bit_cast(u32x4, fa[i]);                                                            \
+          const u32x4 z = {0u, 0u, 0u, 0u};                                                                      \
+          v = kill ? z : v;                                                                                      \
+          fa[i] = __builtin_bit_cast(bf16x8, v);                                                                 \
+        }                                                                                                        \
+      }                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                           \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);                 \
+    }                                                                                                            \
+  }
+
+  int kt = 0;
+  {
+    const int n_main = nk - (NST - 1);
+    for (; kt + NST <= n_main; kt += NST) {
+#pragma unroll
+      for (int c = 0; c < NST; ++c) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // fragment reads of the previous stage complete (see k_conv_dma)
+        YV1_WAIT_H(NST - 2);
+        __builtin_amdgcn_s_barrier();
+        YV1_ISSUE_H((c + NST - 1) % NST);
+        YV1_MFMA_BLOCK_H(smem + c * STAGE);
+      }
+    }
+  }
+  int cur = 0, nxt = NST - 1;                            // kt is a multiple of NST here
+  for (; kt < nk; ++kt) {
+    const int younger = min(nk - 1 - kt, NST - 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (younger >= 2) { YV1_WAIT_H(2); }
+    else if (younger == 1) { YV1_WAIT_H(1); }
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < nk) YV1_ISSUE_H(nxt);
+    YV1_MFMA_BLOCK_H(smem + cur * STAGE);
+    cur = cur + 1 == NST ? 0 : cur + 1;
+    nxt = nxt + 1 == NST ? 0 : nxt + 1;
+  }
+#undef YV1_MFMA_BLOCK_H
+#undef YV1_SET_ROW_H
+#undef YV1_ISSUE_H
+#undef YV1_WAIT_H
+  __syncthreads();
+  conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
+}
+
 // off ^ (ks << 5), computed where it is used: volatile asm so that the compiler does not hoist the KS variants of every
 // fragment offset out of the K loop into registers (slice 0 needs no instruction)
 __device__ __forceinline__ int frag_off(int off0, int ks) {
@@ -1248,6 +1453,24 @@ int launch_dma(ConvArgs& a, hipStream_t stream) {
   return YV1_OK;
 }
 
+template <int BM, int BN, int BK, int WM, int WN, int NST>
+int launch_h3(ConvArgs& a, hipStream_t stream) {
+  constexpr int CPR = BK / 8;
+  constexpr int STAGE = (BM + 64 / CPR) * BK * 2 + 3 * BN * BK * 2;
+  constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
+  constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
+  constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
+  a.MT = (a.M + BM - 1) / BM;
+  a.NT = a.Cout / BN;
+  auto kern = k_conv_h3<BM, BN, BK, WM, WN, NST>;
+  if (LDS > 64 * 1024) YV1_SET_MAX_LDS(kern, LDS);
+  const int flip = a.bh < 0 ? 1 : 0;
+  yv1_cfg_note("k_conv_h3<%d,%d,%d,%d,%d,%d>%s", BM, BN, BK, WM, WN, NST, flip ? " flipped" : "");
+  hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(256), LDS, stream, a, flip);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
@@ -1304,8 +1527,38 @@ int env_int(const char* name, int dflt) {
 // dispatch() and for yv1_conv2d_stats_rows(), which must agree on the number of statistic partial rows.
 struct ConvPlan { int kind, bm, bn, bk, nst; };
 
-ConvPlan plan_conv(int M, int Cout, int Cin, int taps) {
+// 3x3, stride 1, pad 1, same-size output (forward, or the data gradient of such a convolution): k_conv_h3's geometry
+bool is_s1p1_3x3(const ConvArgs& a) {
+  return a.R == 3 && a.S == 3 && a.log2d == 0 && a.ah == 1 && a.aw == 1 && a.os == 1 && a.P == a.IH && a.Q == a.IW &&
+         a.wr0 == 0 && a.ws0 == 0 && a.wrs == 1 && a.wss == 1 && a.WS == 3 && a.Kw == 9 * a.Cin &&
+         ((a.bh == 1 && a.ch == -1 && a.bw == 1 && a.cw == -1) || (a.bh == -1 && a.ch == 1 && a.bw == -1 && a.cw == 1));
+}
+
+ConvPlan plan_conv(int M, int Cout, int Cin, int taps, bool s1p1 = false) {
   ConvPlan p;
+  {
+    // kind 3 = k_conv_h3 (the three taps of a filter row off one A tile).  YV1_CONV_H3=0 turns it off, YV1_CONV_H3_NST
+    // forces its ring depth (tuning)
+    static int h3 = -1, h3nst = 0, h3min = 0, h3bm = 0;
+    if (h3 < 0) {
+      h3 = env_int("YV1_CONV_H3", 1); h3nst = env_int("YV1_CONV_H3_NST", 0); h3min = env_int("YV1_CONV_H3_MIN_TILES", 192);
+      h3bm = env_int("YV1_CONV_H3_BM", 0);
+    }
+    // measured per layer at batch 64 (tools/bench_h3.py, gpurun_out/r3e): forward 128 -> 32 (DenseNet growth) 168 -> 113 us
+    // @112, 51 -> 36 @56, 19 -> 12 @28; 64 -> 64 @112 108 -> 94 (dgrad 126 -> 108) with two stages; 128 -> 128 @56 105 -> 93
+    // (91 -> 85); level on 512 -> 512 @14; SLOWER where K per tap is one 32-channel block (the data gradient of the growth
+    // convolutions: 28 -> 34 us @56) and against the 128x256 / 256x256 tiles of 256 -> 256 @28 (80 vs 83): those keep the ring
+    // kernels.
+    if (h3 && s1p1 && taps == 9 && Cin % 64 == 0 && !(Cout == 256 && M <= 60000)) {
+      int bm = 128, bn = 0, bk = 32, nst = 2;
+      if (Cout % 128 == 0) { bn = 128; }
+      else if (Cout % 64 == 0) { bn = 64; if (h3bm == 256) bm = 256; }
+      else if (Cout % 32 == 0) { bn = 32; bk = 64; if (h3bm == 256) bm = 256; }
+      if ((h3nst == 2 || h3nst == 3) && bm == 128) nst = h3nst;
+      const long long tiles = (long long)((M + bm - 1) / bm) * (bn ? Cout / bn : 0);
+      if (bn && tiles >= h3min) { p.kind = 3; p.bm = bm; p.bn = bn; p.bk = bk; p.nst = nst; return p; }
+    }
+  }
   static int dma = -1, fbk = -1, ps = -1;
   if (dma < 0) {
     dma = env_int("YV1_CONV_DMA", 1);       // 0: register-staged loop; 2/3/4: force a stage count
@@ -1349,8 +1602,12 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps) {
     // fetched once per 256 pixel rows), BK 32 in a three-stage ring (96 KB): measured +11-13 % over 128x256 on 256->256
     // 3x3 @28 and on its stride-2 sibling, +9 % on 1024->256 (four stages, BK 64 in two stages, and 256x128 / 128x256 eight-wave
     // tiles were all slower; 196 tiles on 256 CUs is what caps this shape)
+    // Round 3: the default is chosen by STEP time, not by the kernel's own: alone the 256x256 tile wins (+11-13 %), inside
+    // the training step it loses 0.3-0.7 % (2915-2932 vs 2907-2910 img/s interleaved, round 2: 2969-2972 vs 2951-2962) -- one
+    // eight-wave workgroup per CU leaves the weight-gradient stream nothing to run beside.  YV1_CONV_T256=1 selects it
+    // (the per-layer tables in profiles/ name which tile they were taken with).
     static int t256 = -1;
-    if (t256 < 0) t256 = env_int("YV1_CONV_T256", 1);
+    if (t256 < 0) t256 = env_int("YV1_CONV_T256", 0);
     if (p.kind == 2 && t256 && M >= 256 * 128) { p.bm = 256; p.bn = 256; p.bk = 32; p.nst = 3; return p; }
     p.bn = 256; p.bk = 32; p.nst = 3;
     return p;
@@ -1388,7 +1645,17 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     if (dbg < 0) dbg = env_int("YV1_CONV_DBG", 0);
     a.dbg = dbg;
   }
-  ConvPlan p = plan_conv(a.M, a.Cout, a.Cin, a.R * a.S);
+  ConvPlan p = plan_conv(a.M, a.Cout, a.Cin, a.R * a.S, is_s1p1_3x3(a));
+  if (p.kind == 3) {
+#define YV1_H3_CASE(BN_, BK_, WM_, WN_)                                                                          \
+    if (p.bm == 128 && p.bn == BN_ && p.bk == BK_) return p.nst == 3 ? launch_h3<128, BN_, BK_, WM_, WN_, 3>(a, stream) \
+                                                                     : launch_h3<128, BN_, BK_, WM_, WN_, 2>(a, stream);
+    YV1_H3_CASE(128, 32, 2, 2) YV1_H3_CASE(64, 32, 2, 2) YV1_H3_CASE(32, 64, 4, 1)
+#undef YV1_H3_CASE
+    if (p.bm == 256 && p.bn == 64 && p.bk == 32) return launch_h3<256, 64, 32, 4, 1, 2>(a, stream);
+    if (p.bm == 256 && p.bn == 32 && p.bk == 64) return launch_h3<256, 32, 64, 4, 1, 2>(a, stream);
+    return YV1_ERR_UNSUPPORTED;
+  }
   // The shortcut-adding dgrad (yv1_conv2d_dgrad_add_masked_nhwc_bf16) streams three 4p-wide tensors per tile through a
   // generic epilogue.  One tile per workgroup, whose epilogue fetches the shortcut operands of all its store passes up front,
   // beats the persistent form (which waits once per 16-row group): 198 vs 249 us at 112x112, 122 vs 148 us at 56x56,
@@ -1597,10 +1864,10 @@ extern "C" int yv1_conv2d_dgrad_add_masked_nhwc_bf16(const void* dy, const void*
   return dispatch(a, stream);
 }
 
-extern "C" int yv1_conv2d_stats_rows(int M, int Cout, int Cin, int k) {
+extern "C" int yv1_conv2d_stats_rows(int M, int Cout, int Cin, int k, int stride, int pad) {
   // number of partial rows the forward kernel writes for this shape (same plan as dispatch()): one per pixel tile, or
   // one per workgroup slot for the persistent kernel
-  const ConvPlan p = plan_conv(M, Cout, Cin, k * k);
+  const ConvPlan p = plan_conv(M, Cout, Cin, k * k, k == 3 && stride == 1 && pad == 1);
   const int MT = (M + p.bm - 1) / p.bm;
   if (p.kind == 2) {
     int per_cu = 0;                                            // statistics are written by the PLAIN (training) form only

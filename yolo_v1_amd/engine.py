@@ -83,6 +83,10 @@ class HipBackbone(nn.Module):
         # weight gradients of the last N residual blocks of the backward (+ the stem) run on the MAIN stream (see
         # OriginResNet._run_backward); measured on ResNet-50 at batch 64
         self.wgrad_main_tail = int(os.environ.get("YV1_WGRAD_MAIN_TAIL", "0"))
+        # weight gradients of the last N blocks of the backward (+ the stem) stay on the side stream but use the split-K width
+        # tuned for kernels that run ALONE: the main chain has ended by the time the side stream gets to them
+        # (measured, interleaved: 0 / 2 / 3 / 5 / 8 / 12 blocks -> 2909-2912 / 2920-2921 / 2919-2924 / 2918 / 2917-2921 / 2900 img/s)
+        self.wgrad_wide_tail = int(os.environ.get("YV1_WGRAD_WIDE_TAIL", "3"))
         self.bn_dual = os.environ.get("YV1_BN_DUAL", "1") != "0"         # projection blocks: bn3 + downsample BN backward in one pass
         self.fused_eval = os.environ.get("YV1_FUSED_EVAL", "1") != "0"   # eval(): BatchNorm folded into the conv epilogue
         # training: run the forward convolutions on the fp8 (e4m3) MFMA path -- "fp8 forward GEMMs, bf16 backward"

@@ -142,7 +142,7 @@ def conv_fwd(x, w, y, want_stats=True):
     M = y.npix
     stats = None
     if want_stats:
-        rows = lib().yv1_conv2d_stats_rows(M, w.Opad, w.Ipad, w.k)
+        rows = lib().yv1_conv2d_stats_rows(M, w.Opad, w.Ipad, w.k, w.stride, w.pad)
         stats = _f32(rows * 2 * w.Opad, dev).view(rows, 2, w.Opad)
     check(lib().yv1_conv2d_fwd_nhwc_bf16(x.p, ptr(w.fwd), y.p, x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, y.ld, w.k, w.stride,
                                          w.pad, ptr(stats), stream_ptr(dev)), "yv1_conv2d_fwd_nhwc_bf16")
@@ -306,6 +306,7 @@ class SideStream:
         self.main = torch.cuda.current_stream(device)
         self.side = _side_stream_for(device) if enabled else None
         self.keep = []
+        self.wide = False                    # conv_wgrad: use the split-K width tuned for kernels that run alone
 
     def mark(self):
         """Event at the current end of the main stream: ``run(..., after=mark)`` orders side work after THIS point, so
@@ -432,8 +433,9 @@ def conv_wgrad(x, dy, w, side=None, after=None):
     wsb = L.yv1_conv2d_wgrad_workspace_bytes(x.N, dy.H, dy.W, w.Ipad, w.Opad, w.k)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
 
-    # beside the main stream's kernels a narrower split-K wins, alone on the device the wider one (see yv1.h)
-    overlapped = side is not None and side.side is not None
+    # beside the main stream's kernels a narrower split-K wins, alone on the device the wider one (see yv1.h); ``side.wide``:
+    # this stretch of the side stream runs after the main chain has ended (the tail of the backward) -- alone on the device
+    overlapped = side is not None and side.side is not None and not getattr(side, "wide", False)
     fn = L.yv1_conv2d_wgrad_shared_nhwc_bf16 if overlapped else L.yv1_conv2d_wgrad_nhwc_bf16
 
     def launch():
