@@ -832,273 +832,6 @@ k_conv_h3(ConvArgs a, int flip) {
   conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
 }
 
-// ---- k_conv_h3 with the WEIGHTS resident in LDS, persistent workgroups (round 3) -----------------------------------
-// For the 3x3 layers whose whole filter bank fits beside the A ring -- Cout x 9 x Cin x 2 B = 73.7 KB: DenseNet's growth
-// convolutions (128 -> 32) and ResNet's 64 -> 64 -- the weight tap tiles were 41-57 % of what k_conv_h3 still fills per
-// stage, the same 73.7 KB for every 128-pixel tile.  Here one workgroup per CU loads the filter bank ONCE ([tap][Cout][Cin],
-// swizzled like a B tile) and walks the pixel tiles wg, wg + G, ...; a stage is an A tile alone (BM + 2 pixels x all
-// Cin channels of one filter row), three stages per tile, the loader runs NST-1 stages ahead ACROSS tile boundaries, so the
-// next tile's first rows land under the epilogue.  Epilogue per wave through a private staging area (16 rows at a time),
-// BatchNorm statistic partials accumulated in registers and written once per workgroup (`slots` rows), as k_conv_ps does.
-// The counted waits are conservative after an epilogue (they do not discount its stores: a wait may then also retire the
-// first pieces of the following stage) -- correct for any store count.
-template <int BN, int CIN, int WM, int WN, int NST>
-__global__ void __launch_bounds__(256, 1) k_conv_h3ws(ConvArgs a, int flip) {
-  constexpr int BM = 128, NTH = 256, BK = CIN;
-  static_assert(WM * WN == 4, "four waves");
-  constexpr int CPR = BK / 8;                            // 16-B chunks per pixel
-  constexpr int RPP = NTH / CPR;                         // rows per DMA pass
-  static_assert(BM % RPP == 0 && (9 * BN) % RPP == 0, "whole passes");
-  constexpr int A_FULL = BM / RPP;
-  constexpr int XROWS = 64 / CPR;                        // rows of wave 0's extra 1-KB piece (>= 2)
-  constexpr int A_BYTES = (BM + XROWS) * BK * 2;
-  constexpr int W_BYTES = 9 * BN * BK * 2;
-  constexpr int W_PASSES = 9 * BN / RPP;
-  constexpr int LPS = A_FULL;                            // DMA pieces per stage and wave (wave 0: + 1)
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int KS = BK / 16;
-  constexpr int CW = BN / WN, CPW = CW / 8;
-  constexpr int SPITCH = (CW / 2 % 32 == 16) ? CW * 2 : CW * 2 + 64;
-  constexpr int SROWS = 16, SPASSES = SROWS * CPW / 64;
-  static_assert(SROWS * CPW % 64 == 0 && SPASSES >= 1, "staging passes");
-  constexpr int STG_BYTES = 4 * SROWS * SPITCH;
-  static_assert((NST - 1) * (LPS + 1) < 64, "vmcnt is a 6-bit counter");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  unsigned char* const sw = smem;                        // filter bank
-  unsigned char* const sring = smem + W_BYTES;           // NST A stages
-  unsigned char* const sstg = sring + NST * A_BYTES;     // per-wave staging
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;
-  const int W = a.IW, H = a.IH;
-  const int G = gridDim.x;
-  const int slot_id = blockIdx.x;
-
-  const int slot = tid % CPR, rrow = tid / CPR;
-  const int lchunk = swz<BK>(rrow, slot);
-  const int piece_row0 = (wid * 64) / CPR;
-
-  // ---- filter bank: LDS row R = tap * BN + o  <-  weight row o, loop tap (r, s) = weight tap (flip ? 2-r : r, ...)
-#pragma unroll 1
-  for (int p = 0; p < W_PASSES; ++p) {
-    const int R = rrow + p * RPP;
-    const int tap = R / BN, o = R - tap * BN;
-    const int r_ = tap / 3, s_ = tap - r_ * 3;
-    const int wr = flip ? 2 - r_ : r_, ws = flip ? 2 - s_ : s_;
-    const bf16_t* src = a.W + ((size_t)o * a.Kw + (wr * 3 + ws) * a.Cin + lchunk * 8);
-    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sw + (piece_row0 + p * RPP) * (BK * 2)), 16, 0, 0);
-  }
-
-  // ---- loader state (runs ahead of the MFMA loop, across tile boundaries)
-  int ld_t = slot_id, ld_r = 0;
-  int pcs[A_FULL + 1], ys[A_FULL + 1];
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
-#define YV1_SET_TILE_W()                                                                                         \
-  {                                                                                                              \
-    _Pragma("unroll") for (int i = 0; i <= A_FULL; ++i) {                                                        \
-      const int j = (i < A_FULL) ? rrow + i * RPP : BM + rrow;                                                   \
-      const int pc = ld_t * BM - 1 + j;                                                                          \
-      pcs[i] = (pc >= 0 && pc < a.M) ? pc : -1;                                                                  \
-      ys[i] = pc >= 0 ? (pc / W) % H : 0;                                                                        \
-    }                                                                                                            \
-  }
-#define YV1_ISSUE_W(STG_)                                                                                        \
-  {                                                                                                              \
-    unsigned char* sa_ = sring + (STG_) * A_BYTES;                                                               \
-    _Pragma("unroll") for (int i = 0; i < A_FULL; ++i) {                                                         \
-      const int yy = ys[i] + ld_r - 1;                                                                           \
-      const bool ok = pcs[i] >= 0 && yy >= 0 && yy < H;                                                          \
-      const bf16_t* src = ok ? a.X + ((size_t)(pcs[i] + (ld_r - 1) * W) * a.ldx + lchunk * 8) : zsrc;            \
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sa_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
-    }                                                                                                            \
-    if (wid == 0) {                                                                                              \
-      const int yy = ys[A_FULL] + ld_r - 1;                                                                      \
-      const bool ok = pcs[A_FULL] >= 0 && yy >= 0 && yy < H;                                                     \
-      const bf16_t* src = ok ? a.X + ((size_t)(pcs[A_FULL] + (ld_r - 1) * W) * a.ldx + lchunk * 8) : zsrc;       \
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(sa_ + BM * (BK * 2)), 16, 0, 0);              \
-    }                                                                                                            \
-    if (++ld_r == 3) {                                                                                           \
-      ld_r = 0;                                                                                                  \
-      ld_t += G;                                                                                                 \
-      if (ld_t < a.MT) YV1_SET_TILE_W();                                                                         \
-    }                                                                                                            \
-  }
-#define YV1_WAIT_W(YOUNGER_)                                                                                     \
-  {                                                                                                              \
-    if (wid == 0) wait_vmcnt<(YOUNGER_) * (LPS + 1)>(); else wait_vmcnt<(YOUNGER_) * LPS>();                     \
-  }
-
-  const int l31 = lane & 31, lh = lane >> 5;
-  int fa_off[TM][3], fb_off[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int mrow = wm * (BM / WM) + i * 32 + l31;
-#pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
-      const int row = mrow + s_;
-      fa_off[i][s_] = row * (BK * 2) + swz<BK>(row, lh) * 16;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int row = wn * CW + j * 32 + l31;
-    fb_off[j] = row * (BK * 2) + swz<BK>(row, lh) * 16;
-  }
-  float st_s[TN], st_ss[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { st_s[j] = 0.f; st_ss[j] = 0.f; }
-  unsigned char* stg = sstg + wid * (SROWS * SPITCH);
-  const bool odd = lane & 1;
-
-  const int my_tiles = slot_id < a.MT ? (a.MT - slot_id + G - 1) / G : 0;
-  const int nstage = 3 * my_tiles;
-  if (my_tiles > 0) YV1_SET_TILE_W();
-  // the filter bank must have landed before the first MFMA: it is OLDER than every A piece, so the first stage's counted
-  // wait covers it
-#pragma unroll
-  for (int p = 0; p < NST - 1; ++p)
-    if (p < nstage) YV1_ISSUE_W(p);
-
-  int cur = 0, nxt = NST - 1, k = 0;
-  for (int mt = slot_id; mt < a.MT; mt += G) {
-    const int m0 = mt * BM;
-    bool mleft[TM], mright[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int x = (m0 + wm * (BM / WM) + i * 32 + l31) % W;
-      mleft[i] = x == 0;
-      mright[i] = x == W - 1;
-    }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-#pragma unroll
-    for (int r_ = 0; r_ < 3; ++r_, ++k) {
-      const int younger = min(nstage - 1 - k, NST - 2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // fragment / staging reads of the previous stage complete
-      if (younger >= 1) { YV1_WAIT_W(1); } else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();                              // stage k landed for everyone; everyone left stage nxt
-      if (k + NST - 1 < nstage) YV1_ISSUE_W(nxt);
-      const unsigned char* base = sring + cur * A_BYTES;
-#pragma unroll
-      for (int s_ = 0; s_ < 3; ++s_) {
-        const unsigned char* wb = sw + (r_ * 3 + s_) * (BN * BK * 2);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          bf16x8 fa[TM], fb[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(base + (fa_off[i][s_] ^ (ks << 5)));
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wb + (fb_off[j] ^ (ks << 5)));
-          if (s_ != 1) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-              const bool kill = s_ == 0 ? mleft[i] : mright[i];
-              u32x4 v = __builtin_bit_cast(u32x4, fa[i]);
-              const u32x4 z = {0u, 0u, 0u, 0u};
-              v = kill ? z : v;
-              fa[i] = __builtin_bit_cast(bf16x8, v);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-      }
-      cur = cur + 1 == NST ? 0 : cur + 1;
-      nxt = nxt + 1 == NST ? 0 : nxt + 1;
-    }
-
-    // ---- epilogue, per wave: statistics in registers, 16 rows at a time through the wave's staging area
-    if (a.stats) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float v = acc[i][j][e];
-            s += v;
-            ss += v * v;
-          }
-        st_s[j] += s;
-        st_ss[j] += ss;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = j * 32 + l31;
-#pragma unroll
-          for (int e8 = 0; e8 < 8; e8 += 2) {
-            const int e = hb * 8 + e8;
-            const float mine_lo = acc[i][j][e], mine_hi = acc[i][j][e + 1];
-            const float send = odd ? mine_lo : mine_hi;
-            const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
-            const int lrow = ((e8 + (odd ? 1 : 0)) & 3) + 8 * (e8 >> 2) + 4 * lh;
-            const unsigned v = odd ? cvt_pk_bf16(recv, mine_hi) : cvt_pk_bf16(mine_lo, recv);
-            *reinterpret_cast<unsigned*>(stg + lrow * SPITCH + (col & ~1) * 2) = v;
-          }
-        }
-        // same wave wrote the rows and LDS operations of a wave complete in order: no barrier
-#pragma unroll
-        for (int sp = 0; sp < SPASSES; ++sp) {
-          const int idx = lane + sp * 64;
-          const int row = idx / CPW, cc = idx - row * CPW;
-          const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + cc * 16);
-          const int m = m0 + wm * (BM / WM) + i * 32 + hb * 16 + row;
-          if (m < a.M) *reinterpret_cast<uint4*>(a.Y + (size_t)m * a.ldy + wn * CW + cc * 8) = v;
-        }
-      }
-    }
-  }
-#undef YV1_SET_TILE_W
-#undef YV1_ISSUE_W
-#undef YV1_WAIT_W
-
-  if (a.stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(sring);               // [WM][2][BN]
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = st_s[j], ss = st_ss[j];
-      s += __shfl_xor(s, 32, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      if (lh == 0) {
-        const int c = wn * CW + j * 32 + l31;
-        red[(wm * 2 + 0) * BN + c] = s;
-        red[(wm * 2 + 1) * BN + c] = ss;
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s += red[(w * 2 + 0) * BN + tid];
-        ss += red[(w * 2 + 1) * BN + tid];
-      }
-      float* o = a.stats + (size_t)slot_id * 2 * a.Cout + tid;
-      o[0] = s;
-      o[a.Cout] = ss;
-    }
-  }
-}
-
 // off ^ (ks << 5), computed where it is used: volatile asm so that the compiler does not hoist the KS variants of every
 // fragment offset out of the K loop into registers (slice 0 needs no instruction)
 __device__ __forceinline__ int frag_off(int off0, int ks) {
@@ -1738,34 +1471,6 @@ int launch_h3(ConvArgs& a, hipStream_t stream) {
   return YV1_OK;
 }
 
-// workgroups of a k_conv_h3ws launch (= its statistic partial rows): one per CU, at most one per pixel tile
-int h3ws_slots(int M) {
-  const int MT = (M + 127) / 128;
-  const int n = ps_ncu();
-  return MT < n ? MT : n;
-}
-
-template <int BN, int CIN, int WM, int WN, int NST>
-int launch_h3ws(ConvArgs& a, hipStream_t stream) {
-  constexpr int CPR = CIN / 8;
-  constexpr int A_BYTES = (128 + 64 / CPR) * CIN * 2, W_BYTES = 9 * BN * CIN * 2;
-  constexpr int CW = BN / WN;
-  constexpr int SPITCH = (CW / 2 % 32 == 16) ? CW * 2 : CW * 2 + 64;
-  constexpr size_t LDS = W_BYTES + NST * A_BYTES + 4 * 16 * SPITCH;
-  static_assert(LDS <= 160 * 1024, "LDS");
-  if (a.Cout != BN || a.Cin != CIN) return YV1_ERR_UNSUPPORTED;
-  a.MT = (a.M + 127) / 128;
-  a.NT = 1;
-  a.slots = h3ws_slots(a.M);
-  auto kern = k_conv_h3ws<BN, CIN, WM, WN, NST>;
-  YV1_SET_MAX_LDS(kern, LDS);
-  const int flip = a.bh < 0 ? 1 : 0;
-  yv1_cfg_note("k_conv_h3ws<%d,%d,%d,%d,%d>%s", BN, CIN, WM, WN, NST, flip ? " flipped" : "");
-  hipLaunchKernelGGL(kern, dim3(a.slots), dim3(256), LDS, stream, a, flip);
-  YV1_LAUNCH_CHECK();
-  return YV1_OK;
-}
-
 template <int BM, int BN, int BK, int WM, int WN>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
@@ -1829,7 +1534,7 @@ bool is_s1p1_3x3(const ConvArgs& a) {
          ((a.bh == 1 && a.ch == -1 && a.bw == 1 && a.cw == -1) || (a.bh == -1 && a.ch == 1 && a.bw == -1 && a.cw == 1));
 }
 
-ConvPlan plan_conv(int M, int Cout, int Cin, int taps, bool s1p1 = false, bool allow_ws = true) {
+ConvPlan plan_conv(int M, int Cout, int Cin, int taps, bool s1p1 = false) {
   ConvPlan p;
   {
     // kind 3 = k_conv_h3 (the three taps of a filter row off one A tile).  YV1_CONV_H3=0 turns it off, YV1_CONV_H3_NST
@@ -1844,13 +1549,9 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps, bool s1p1 = false, bool a
     // (91 -> 85); level on 512 -> 512 @14; SLOWER where K per tap is one 32-channel block (the data gradient of the growth
     // convolutions: 28 -> 34 us @56) and against the 128x256 / 256x256 tiles of 256 -> 256 @28 (80 vs 83): those keep the ring
     // kernels.
-    // kind 4 = k_conv_h3ws: the filter bank resident in LDS (YV1_CONV_H3WS=0 turns it off)
-    static int h3ws = -1;
-    if (h3ws < 0) h3ws = env_int("YV1_CONV_H3WS", 1);
-    if (h3 && h3ws && allow_ws && s1p1 && taps == 9 && ((Cout == 32 && Cin == 128) || (Cout == 64 && Cin == 64)) && (M + 127) / 128 >= h3min) {
-      p.kind = 4; p.bm = 128; p.bn = Cout; p.bk = Cin; p.nst = Cin == 128 ? 2 : 3;
-      return p;
-    }
+    // (A weight-stationary persistent form for the two shapes whose filter bank fits in LDS -- 128 -> 32 and 64 -> 64:
+    // 73.7 KB -- was built and measured: one workgroup per CU cannot hide its LDS round trips and dependent-MFMA latency;
+    // 147-165 us against 113 here on 128 -> 32 @112 even with two fragment buffers and two accumulator sets.  Removed.)
     if (h3 && s1p1 && taps == 9 && Cin % 64 == 0 && !(Cout == 256 && M <= 60000)) {
       int bm = 128, bn = 0, bk = 32, nst = 2;
       if (Cout % 128 == 0) { bn = 128; }
@@ -1948,13 +1649,6 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     a.dbg = dbg;
   }
   ConvPlan p = plan_conv(a.M, a.Cout, a.Cin, a.R * a.S, is_s1p1_3x3(a));
-  if (p.kind == 4) {
-    if (!a.escale && !a.erelu && !a.AS && !a.ERES && !a.accumulate) {          // the plain (training) epilogue only
-      if (p.bn == 32) return launch_h3ws<32, 128, 4, 1, 2>(a, stream);
-      return launch_h3ws<64, 64, 2, 2, 3>(a, stream);
-    }
-    p = plan_conv(a.M, a.Cout, a.Cin, a.R * a.S, true, false);                 // other epilogues: k_conv_h3 / the ring kernels
-  }
   if (p.kind == 3) {
 #define YV1_H3_CASE(BN_, BK_, WM_, WN_)                                                                          \
     if (p.bm == 128 && p.bn == BN_ && p.bk == BK_) return p.nst == 3 ? launch_h3<128, BN_, BK_, WM_, WN_, 3>(a, stream) \
@@ -2178,7 +1872,6 @@ extern "C" int yv1_conv2d_stats_rows(int M, int Cout, int Cin, int k, int stride
   // one per workgroup slot for the persistent kernel
   const ConvPlan p = plan_conv(M, Cout, Cin, k * k, k == 3 && stride == 1 && pad == 1);
   const int MT = (M + p.bm - 1) / p.bm;
-  if (p.kind == 4) return h3ws_slots(M);
   if (p.kind == 2) {
     int per_cu = 0;                                            // statistics are written by the PLAIN (training) form only
 #define YV1_RING_CASE(BM_, BN_, BK_, WM_, WN_, NST_)                                                             \
