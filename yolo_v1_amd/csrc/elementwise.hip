@@ -247,10 +247,14 @@ __device__ __forceinline__ void block_column_reduce(float (&acc)[NCOL][NV][8], i
   for (int j = 0; j < NCOL; ++j) {
     const int col = tx + j * TX;
     if (col < CH) {
+      // two 16-byte stores per vector: as eight dword stores (lane stride 32 B) these were 8-way bank conflicts, 71 % of the
+      // kernels' LDS-active cycles (profiles/r02_pmc_sq_summary.txt); C % 8 == 0 keeps them aligned
 #pragma unroll
-      for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) red[((size_t)ty * NV + v) * C + col * 8 + k] = acc[j][v][k];
+      for (int v = 0; v < NV; ++v) {
+        float4* dst = reinterpret_cast<float4*>(&red[((size_t)ty * NV + v) * C + col * 8]);
+        dst[0] = make_float4(acc[j][v][0], acc[j][v][1], acc[j][v][2], acc[j][v][3]);
+        dst[1] = make_float4(acc[j][v][4], acc[j][v][5], acc[j][v][6], acc[j][v][7]);
+      }
     }
   }
   __syncthreads();
