@@ -219,6 +219,34 @@ int yv1_bn_bwd_finalize_apply_dual(const float* partials, const float* partials2
                                    const float* mean, const float* invstd, void* dy, int lddy, const void* y2, int ldy2,
                                    const float* mean2, const float* invstd2, void* dy2, int lddy2, long long npix, int C,
                                    int mask_mode, unsigned* sync, unsigned* fault, yv1_stream_t stream);
+/* "bn3's backward as algebra" (round 3).  An identity-shortcut Bottleneck ends
+ * out = relu(bn3(conv3(z2)) + x) (OriginResNet.py:97-105); conv3 is pointwise, so BatchNorm-3's backward commutes with it:
+ * from the MASKED output gradient gm, T = gm^T z2 (yv1_conv2d_wgrad_nhwc_bf16 fed gm), G = z2^T z2 and column sums,
+ *   dgamma/dbeta/k1/k2/k3*is  <- yv1_bn3_coeffs       (no pass over y3)
+ *   wcat = [diag(k1) W3 ; -W3^T diag(k3*is) W3], bias  <- yv1_bn3_build
+ *   dz2 = [gm | z2] wcat^T + bias                      <- yv1_conv2d_dgrad_cat_bias_nhwc_bf16 (second K source, bias epilogue)
+ *   dW3                                                <- yv1_bn3_dw
+ * and gm itself, with its column sums, comes out of the conv1 data gradient of the block above
+ * (yv1_conv2d_dgrad_add_masked_out_nhwc_bf16: output mask + per-tile sums in the epilogue).  The stand-alone
+ * yv1_bn_bwd_reduce / _finalize / _apply passes over the 4p-wide tensors do not run; dy3 is never formed. */
+int yv1_conv2d_dgrad_add_masked_out_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx,
+                                              int Cin, int Cout, int lddy, const void* g, int ldg, const void* relu_mask,
+                                              int ldmask, const void* out_mask, int ldom, float* gsum,
+                                              yv1_stream_t stream);
+int yv1_conv2d_dgrad_out_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin, int Cout,
+                                   int lddy, int stride, int accumulate, const void* out_mask, int ldom, float* gsum,
+                                   yv1_stream_t stream);   /* 1x1 pad-0 data gradient (stride 1 | 2) + output mask + sums */
+int yv1_conv2d_dgrad_gsum_rows(int M, int Cin, int Cout);
+int yv1_conv2d_dgrad_cat_bias_nhwc_bf16(const void* g, int ldg, int C1, const void* z, int ldz, int C2, const void* wcat,
+                                        const float* one, const float* bias, void* dx, int lddx, int Cdx, int N, int H, int W,
+                                        yv1_stream_t stream);
+int yv1_bn3_coeffs(const float* gsum, int rows, const float* T, const void* w3, int p, int C4, const float* mean,
+                   const float* invstd, const float* gamma, float count, float* dgamma, float* dbeta, float* k1, float* k2,
+                   float* k3is, yv1_stream_t stream);
+int yv1_bn3_build(const void* w3, int p, int C4, const float* k1, const float* k2, const float* k3is, const float* mean,
+                  void* wcat, float* bias, yv1_stream_t stream);
+int yv1_bn3_dw(const float* T, const float* G, const float* sz_partials, int rows, const void* w3, int p, int C4,
+               const float* k1, const float* k2, const float* k3is, const float* mean, float* dW, yv1_stream_t stream);
 /* BatchNorm(+ReLU) backward behind the stem's 3x3/2 max pool (OriginResNet.py:174-177, OriginDenseNet.py:120-128; autograd
  * of nn.MaxPool2d + nn.ReLU + nn.BatchNorm2d): dpool [N,OH,OW,C] is the gradient of the pool OUTPUT, pool_idx what
  * yv1_maxpool3x3s2_fwd stored; the pool's backward is gathered on the fly, so the 4x larger gradient of the pool input is

@@ -1,0 +1,198 @@
+"""BatchNorm-3's backward as algebra (round 3; csrc/bn3alg.hip) against the pass-based backward it
+replaces -- autograd of `out = relu(bn3(conv3(z2)) + x)` in an identity-shortcut Bottleneck (OriginResNet.py:97-105).
+
+Pieces, each against a direct restatement:
+  * the conv1 data gradient that stores the block-below's output gradient MASKED and emits its per-tile column sums
+    (`yv1_conv2d_dgrad_add_masked_out_nhwc_bf16`): the stored tensor is BIT-identical to mask(x) applied to
+    `yv1_conv2d_dgrad_add_masked_nhwc_bf16`'s, the sums equal the column sums of what was stored (fp32 order: 1e-5);
+  * `yv1_conv2d_dgrad_cat_bias_nhwc_bf16` ([g | z] wcat^T + bias through the second-K-source loader) against fp32 matmul on
+    the same bf16 operands: rtol 1e-2 / atol 1e-2 x max (the bf16 output rounding);
+  * the whole replacement (T GEMM, coefficients, operand build, data gradient, dW3 assembly) against the pass-based
+    BatchNorm-3 backward + conv3 dgrad/wgrad on the SAME tensors: dbeta 2e-3, dgamma 5e-3 (of the largest; measured 2.6e-3), dz2 and dW3 rel-L2 <= 1e-2 -- the two
+    paths differ by where bf16 rounding happens (dy3 is never rounded here; W' and Q are), 2-3e-3 on the CPU emulation
+    (tools/bn3_algebra_check.py);
+  * a ResNet-50 training step with and without the algebra: the loss identical (the forward is untouched), layer4 / layer5 /
+    head gradients bit-identical (no algebra block above them), every other parameter gradient within rel-L2 1.5e-1 /
+    cosine 0.99 (measured worst 8.2e-2 / 0.9967 at the stem: two valid bf16 roundings 3e-3 apart per block compound through
+    ReLU-gate flips at batch 8), and the step bitwise reproducible run to run.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+
+
+def _mask_from_bits(bits):
+    """bool [M][C] -> ops.ReluMask"""
+    from yolo_v1_amd import ops
+    M, C = bits.shape
+    packed = torch.zeros(M, C // 8, dtype=torch.uint8)
+    bv = bits.view(M, C // 8, 8).to(torch.uint8)
+    for k in range(8):
+        packed |= bv[..., k] << k
+    m = ops.ReluMask(M, C, DEV)
+    m.t.copy_(packed.to(DEV))
+    return m
+
+
+@pytest.mark.parametrize("N,H,p", [(8, 28, 64), (4, 14, 256), (64, 56, 128)])
+def test_masked_output_and_column_sums_of_the_conv1_data_gradient(N, H, p):
+    from yolo_v1_amd import ops
+    C4 = 4 * p
+    g = torch.Generator().manual_seed(p + H)
+    w = (torch.randn(p, C4, 1, 1, generator=g) * (2.0 / C4) ** 0.5).to(torch.bfloat16).float()
+    param = torch.nn.Parameter(w.to(DEV).contiguous(memory_format=torch.channels_last))
+    cw = ops.ConvWeights(param, 1, 1, 0)
+    cw.refresh()
+    dy = ops.Act(torch.randn(N, H, H, p, generator=g).to(torch.bfloat16).to(DEV))
+    gup = ops.Act((torch.randn(N, H, H, C4, generator=g) * 0.1).to(torch.bfloat16).to(DEV))
+    M = N * H * H
+    m_up = _mask_from_bits(torch.rand(M, C4, generator=g) > 0.5)          # this block's own ReLU mask (gates g)
+    bits_out = torch.rand(M, C4, generator=g) > 0.4                        # the block below's ReLU mask (gates dx)
+    m_out = _mask_from_bits(bits_out)
+    ref = ops.new_act(N, H, H, C4, DEV)
+    ops.conv_dgrad_add_masked(dy, cw, ref, gup, m_up)
+    got = ops.new_act(N, H, H, C4, DEV)
+    gsum = ops.conv_dgrad_add_masked_out(dy, cw, got, gup, m_up, out_mask=m_out, want_sum=True)
+    torch.cuda.synchronize()
+    want = torch.where(bits_out.view(N, H, H, C4).to(DEV), ref.t, torch.zeros((), dtype=torch.bfloat16, device=DEV))
+    assert torch.equal(got.t, want)                                        # masking the stored bf16 values: bit-exact
+    cs = want.float().sum((0, 1, 2))
+    assert float((gsum.sum(0) - cs).abs().max()) <= 1e-5 * float(want.float().abs().sum((0, 1, 2)).max()) + 1e-6
+    # premasked g (mask None) == mask applied beforehand
+    gpre = ops.Act(torch.where(_bits(m_up, M, C4).view(N, H, H, C4), gup.t, torch.zeros((), dtype=torch.bfloat16, device=DEV)))
+    got2 = ops.new_act(N, H, H, C4, DEV)
+    ops.conv_dgrad_add_masked_out(dy, cw, got2, gpre, None, out_mask=m_out, want_sum=False)
+    assert torch.equal(got2.t, want)
+
+
+@pytest.mark.parametrize("N,H,p,stride", [(8, 28, 64, 2), (4, 56, 64, 1), (64, 56, 128, 2)])
+def test_masked_output_and_column_sums_of_a_projection_blocks_data_gradient_pair(N, H, p, stride):
+    """The block below a PROJECTION Bottleneck gets its output gradient from two launches: conv1's data gradient (all
+    pixels), then the strided downsample convolution's scatter-accumulate.  Both store masked; their partial sums add up to
+    the column sums of the final tensor."""
+    from yolo_v1_amd import ops
+    Cx = 2 * p                                   # block input width (e.g. 256 -> planes 128, stride 2)
+    g = torch.Generator().manual_seed(3 * p + H + stride)
+    Ho = (H - 1) // stride + 1
+    w1 = torch.nn.Parameter(((torch.randn(p, Cx, 1, 1, generator=g) * 0.1).to(torch.bfloat16).float()).to(DEV)
+                            .contiguous(memory_format=torch.channels_last))
+    wd = torch.nn.Parameter(((torch.randn(4 * p, Cx, 1, 1, generator=g) * 0.1).to(torch.bfloat16).float()).to(DEV)
+                            .contiguous(memory_format=torch.channels_last))
+    c1, cd = ops.ConvWeights(w1, 1, 1, 0), ops.ConvWeights(wd, 1, stride, 0)
+    c1.refresh(); cd.refresh()
+    dy1 = ops.Act(torch.randn(N, H, H, p, generator=g).to(torch.bfloat16).to(DEV))
+    dyd = ops.Act(torch.randn(N, Ho, Ho, 4 * p, generator=g).to(torch.bfloat16).to(DEV))
+    M = N * H * H
+    bits = torch.rand(M, Cx, generator=g) > 0.4
+    m_out = _mask_from_bits(bits)
+    ref = ops.new_act(N, H, H, Cx, DEV)
+    ops.conv_dgrad(dy1, c1, ref, accumulate=False)
+    first = torch.where(bits.view(N, H, H, Cx).to(DEV), ref.t, torch.zeros((), dtype=torch.bfloat16, device=DEV))
+    ref.t.copy_(first)                                                    # the pair's second launch sees the masked tensor
+    ops.conv_dgrad(dyd, cd, ref, accumulate=True)
+    want = torch.where(bits.view(N, H, H, Cx).to(DEV), ref.t, torch.zeros((), dtype=torch.bfloat16, device=DEV))
+    got = ops.new_act(N, H, H, Cx, DEV)
+    s_a = ops.conv_dgrad_out(dy1, c1, got, False, m_out)
+    s_b = ops.conv_dgrad_out(dyd, cd, got, True, m_out)
+    torch.cuda.synchronize()
+    assert torch.equal(got.t, want)
+    cs = want.float().sum((0, 1, 2))
+    tot = s_a.sum(0) + s_b.sum(0)
+    assert float((tot - cs).abs().max()) <= 2e-5 * float(want.float().abs().sum((0, 1, 2)).max()) + 1e-6
+
+
+def _bits(mask, M, C):
+    b = mask.t.view(M, C // 8, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8).view(1, 1, 8)
+    return (b & 1).bool().view(M, C)
+
+
+@pytest.mark.parametrize("N,H,p", [(8, 28, 64), (16, 28, 256)])
+def test_bn3_algebra_matches_the_pass_based_backward(N, H, p):
+    from yolo_v1_amd import ops
+    C4 = 4 * p
+    g = torch.Generator().manual_seed(7 * p + H)
+    M = N * H * H
+    z2 = ops.Act((torch.relu(torch.randn(N, H, H, p, generator=g) * 0.8 + 0.2)).to(torch.bfloat16).to(DEV))
+    w = torch.randn(C4, p, 1, 1, generator=g) * (2.0 / p) ** 0.5
+    conv3 = torch.nn.Parameter(w.to(DEV).contiguous(memory_format=torch.channels_last))
+    w3 = ops.ConvWeights(conv3, 1, 1, 0)
+    w3.refresh()
+    bn3 = torch.nn.BatchNorm2d(C4).to(DEV)
+    with torch.no_grad():
+        bn3.weight.copy_(torch.rand(C4, generator=g) + 0.5)
+    y3 = ops.new_act(N, H, H, C4, DEV)
+    st3 = ops.bn_finalize(ops.conv_fwd(z2, w3, y3, True), M, bn3)
+    x = ops.Act(torch.randn(N, H, H, C4, generator=g).to(torch.bfloat16).to(DEV))
+    out = ops.new_act(N, H, H, C4, DEV)
+    omask = ops.bn_apply(y3, st3, out, relu=True, residual=x, want_mask=True)
+    gout = ops.Act((torch.randn(N, H, H, C4, generator=g) * 1e-2).to(torch.bfloat16).to(DEV))
+    # ---- pass-based: reduce / finalize / apply, conv3 dgrad + wgrad
+    side = ops.SideStream(torch.device(DEV), enabled=False)
+    dy3 = ops.new_act(N, H, H, C4, DEV)
+    dg_ref, db_ref = ops.bn_backward(gout, y3, st3, bn3, dy3, 3, z=omask)
+    dz2_ref = ops.new_act(N, H, H, p, DEV)
+    ops.conv_dgrad(dy3, w3, dz2_ref)
+    dW_ref = ops.conv_wgrad(z2, dy3, w3)
+    # ---- algebra: masked gradient + its column sums, then the four GEMM-side steps
+    gm = ops.Act(torch.where(_bits(omask, M, C4).view(N, H, H, C4), gout.t, torch.zeros((), dtype=torch.bfloat16, device=DEV)))
+    gsum = gm.t.float().sum((0, 1, 2)).view(1, C4).contiguous()
+    dz2 = ops.new_act(N, H, H, p, DEV)
+    dg, db, dW = ops.bn3_algebra_backward(gm, gsum, z2, w3, st3, bn3, conv3, dz2, side)
+    side.join()
+    torch.cuda.synchronize()
+    scale_g = float(dg_ref.abs().max())
+    assert float((db - db_ref).abs().max()) <= 2e-3 * float(db_ref.abs().max()) + 1e-7
+    assert float((dg - dg_ref).abs().max()) <= 5e-3 * scale_g + 1e-7       # the passes read the bf16-ROUNDED y3, the algebra never rounds it
+    print("\np=%d @%d: dz2 rel-L2 %.2e, dW3 rel-L2 %.2e, dgamma max err / max %.2e" % (
+        p, H, _rel(dz2.t, dz2_ref.t), _rel(dW, dW_ref), float((dg - dg_ref).abs().max()) / scale_g))
+    assert _rel(dz2.t, dz2_ref.t) <= 1e-2
+    assert _rel(dW, dW_ref) <= 1e-2
+
+
+def test_training_step_with_and_without_the_algebra():
+    from yolo_v1_amd import ops
+    from yolo_v1_amd.backbones.OriginResNet import resnet50
+    from yolo_v1_amd.utils.YOLODataLoader import synthetic_batch
+    from yolo_v1_amd.v1Loss import YOLOLossV1
+    images, target = synthetic_batch(8, 4, hw=256, device=DEV)
+    runs = []
+    default = ops.BN3_ALGEBRA_MAX_P
+    try:
+        for maxp in (0, 256, 256):               # 256: layer1-3 (the default is 128: layer1-2, the stages where it pays)
+            ops.BN3_ALGEBRA_MAX_P = maxp
+            torch.manual_seed(3)
+            net = resnet50(S=7).to(DEV).train()
+            with torch.no_grad():
+                for n, q in net.named_parameters():
+                    if n.endswith("bn3.weight"):
+                        q.mul_(0.2)
+            crit = YOLOLossV1(8, 4, 2, 20, _quiet=True)
+            loss = crit(net(images), target)
+            loss.backward()
+            torch.cuda.synchronize()
+            runs.append((float(loss.item()), {n: q.grad.detach().clone() for n, q in net.named_parameters()}))
+    finally:
+        ops.BN3_ALGEBRA_MAX_P = default
+    (l0, g0), (l1, g1), (l2, g2) = runs
+    assert l0 == l1 == l2                                                   # the forward is untouched
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n                                 # reproducible run to run
+    worst = ("", 0.0)
+    for n in g0:
+        if n.startswith(("layer4.", "layer5.", "layer6.", "bn_end.")):
+            assert torch.equal(g1[n], g0[n]), n                             # upstream of every algebra block: untouched, bit for bit
+            continue
+        r = _rel(g1[n], g0[n])
+        c = float(torch.nn.functional.cosine_similarity(g1[n].flatten().float(), g0[n].flatten().float(), dim=0))
+        if r > worst[1]:
+            worst = (n, r)
+        # two equally valid bf16 roundings of the same backward, 3e-3 apart per block, through up to ten blocks at batch 8:
+        # ReLU-gate flips compound towards the stem (measured worst: bn1.bias 8.2e-2 / cosine 0.9967)
+        assert r <= 1.5e-1 and c >= 0.99, (n, r, c)
+    print("\nalgebra vs passes: worst parameter-gradient rel-L2 %.2e (%s)" % (worst[1], worst[0]))

@@ -16,6 +16,7 @@ Per Bottleneck (OriginResNet.py:87-107), forward:
     yd = conv1x1(x, stride)    projection shortcut when the shape changes (:159-163)
     out = relu(bn3(y3) + (bn_d(yd) | x))      one fused elementwise kernel
 """
+import torch
 import torch.nn as nn
 
 from .. import _lib, ops
@@ -224,43 +225,58 @@ class ResNet(HipBackbone):
             self._bump_counters(bns)
         return pred, (rec if save else None)
 
-    def block_backward(self, brec, g, grads, side):
+    def _bn3_algebra_ok(self, brec):
+        """Identity-shortcut Bottleneck whose BatchNorm-3 backward can run as algebra (ops.bn3_algebra_backward)."""
+        blk, x, y1 = brec[0], brec[1], brec[2]
+        p = blk.conv1.out_channels
+        return (brec[10] is None and brec[13] is not None and ops.BN3_ALGEBRA_MAX_P > 0 and p % 64 == 0 and
+                p <= ops.BN3_ALGEBRA_MAX_P)
+
+    def block_backward(self, brec, g, grads, side, g_sum=None, below=None):
         """Backward of one Bottleneck: ``g`` is the gradient of the block output; fills ``grads`` and returns the gradient of
-        the block input."""
+        the block input.  ``g_sum``: ``g`` arrives already ReLU-masked with its per-tile column sums (the block above stored
+        it that way): BatchNorm-3 + conv3 run as algebra.  ``below``: the record of the block whose output gradient this
+        block produces, when THAT block wants it masked + summed; returns (g_in, sums or None)."""
         (blk, x, y1, s1, z1, y2, s2, z2, y3, s3, yd, sd, out, omask) = brec
         dev = g.t.device
         N = x.N
         w1, w2, w3 = self.cw(blk.conv1), self.cw(blk.conv2), self.cw(blk.conv3)
         g_in = ops.new_act(N, x.H, x.W, x.C, dev)
-        dy3 = ops.new_act(N, y3.H, y3.W, y3.C, dev)
-        if yd is not None:
-            wd = self.cw(blk.downsample[0])
-            bnd = blk.downsample[1]
-            dyd = ops.new_act(N, yd.H, yd.W, yd.C, dev)
-            # bn3 and the downsample BatchNorm receive the same masked gradient: one reduction + one apply pass for both
-            if self.bn_dual:
-                (grads[blk.bn3.weight], grads[blk.bn3.bias]), (grads[bnd.weight], grads[bnd.bias]) = ops.bn_backward_dual(
-                    g, omask, (y3, s3, blk.bn3, dy3), (yd, sd, bnd, dyd))
-            else:
-                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
-                grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
-        else:
-            # identity shortcut: its contribution to g_in (g where the block output was positive) is added in
-            # the epilogue of conv1's dgrad below
-            grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
-        # the data gradient (critical path) is enqueued BEFORE the weight gradient that reads the same dy: launched
-        # the other way round, the side stream's wgrad workgroups fill the CUs first and the dgrad waits behind
-        # them (50 us per layer in the trace); this way the wgrad runs beside the bandwidth-bound BN kernels.
-        # Inside a captured hipGraph the order decides more: the HIP runtime hands a node's FIRST captured successor the
-        # node's own queue and every further successor another one, so a weight gradient captured before the next
-        # main-chain kernel pushes the main chain onto a new queue -- after four such forks (the projection blocks) it
-        # wrapped around onto the weight gradients' queue and layer2's backward ran serialized with them (DESIGN.md section 7)
-        mk = side.mark()
+        algebra = g_sum is not None
         dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
-        ops.conv_dgrad(dy3, w3, dz2)
-        if yd is not None:
-            grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side, after=mk)
-        grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side, after=mk)
+        if algebra:
+            # bn3's reduce / finalize / apply passes and conv3's ordinary dgrad + wgrad, as four GEMM-side steps
+            (grads[blk.bn3.weight], grads[blk.bn3.bias], grads[blk.conv3.weight]) = ops.bn3_algebra_backward(
+                g, g_sum, z2, w3, s3, blk.bn3, blk.conv3.weight, dz2, side)
+        else:
+            dy3 = ops.new_act(N, y3.H, y3.W, y3.C, dev)
+            if yd is not None:
+                wd = self.cw(blk.downsample[0])
+                bnd = blk.downsample[1]
+                dyd = ops.new_act(N, yd.H, yd.W, yd.C, dev)
+                # bn3 and the downsample BatchNorm receive the same masked gradient: one reduction + one apply pass for both
+                if self.bn_dual:
+                    (grads[blk.bn3.weight], grads[blk.bn3.bias]), (grads[bnd.weight], grads[bnd.bias]) = ops.bn_backward_dual(
+                        g, omask, (y3, s3, blk.bn3, dy3), (yd, sd, bnd, dyd))
+                else:
+                    grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
+                    grads[bnd.weight], grads[bnd.bias] = ops.bn_backward(g, yd, sd, bnd, dyd, 3, z=omask)
+            else:
+                # identity shortcut: its contribution to g_in (g where the block output was positive) is added in
+                # the epilogue of conv1's dgrad below
+                grads[blk.bn3.weight], grads[blk.bn3.bias] = ops.bn_backward(g, y3, s3, blk.bn3, dy3, 3, z=omask)
+            # the data gradient (critical path) is enqueued BEFORE the weight gradient that reads the same dy: launched
+            # the other way round, the side stream's wgrad workgroups fill the CUs first and the dgrad waits behind
+            # them (50 us per layer in the trace); this way the wgrad runs beside the bandwidth-bound BN kernels.
+            # Inside a captured hipGraph the order decides more: the HIP runtime hands a node's FIRST captured successor the
+            # node's own queue and every further successor another one, so a weight gradient captured before the next
+            # main-chain kernel pushes the main chain onto a new queue -- after four such forks (the projection blocks) it
+            # wrapped around onto the weight gradients' queue and layer2's backward ran serialized with them (DESIGN.md section 7)
+            mk = side.mark()
+            ops.conv_dgrad(dy3, w3, dz2)
+            if yd is not None:
+                grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side, after=mk)
+            grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side, after=mk)
         dy2 = ops.new_act(N, y2.H, y2.W, y2.C, dev)
         grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
         mk = side.mark()
@@ -270,14 +286,26 @@ class ResNet(HipBackbone):
         dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
         grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
         mk = side.mark()
-        if yd is not None:
+        sums = None
+        if yd is not None and below is not None:
+            # the block below runs its bn3 backward as algebra: both data gradients store its output gradient masked by ITS
+            # ReLU mask and report the column sums of what they added
+            s_a = ops.conv_dgrad_out(dy1, w1, g_in, False, below[13])
+            s_b = ops.conv_dgrad_out(dyd, wd, g_in, True, below[13])
+            sums = torch.cat([s_a, s_b], 0)
+        elif yd is not None:
             ops.conv_dgrad(dy1, w1, g_in, accumulate=False)
             ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate
+        elif below is not None or algebra:
+            # g is added unmasked-or-premasked; the block BELOW gets its output gradient masked + summed when it asks for it
+            sums = ops.conv_dgrad_add_masked_out(dy1, w1, g_in, g, None if algebra else omask,
+                                                 out_mask=below[13] if below is not None else None,
+                                                 want_sum=below is not None)
         else:
             ops.conv_dgrad_add_masked(dy1, w1, g_in, g, omask)
         grads[blk.conv1.weight] = ops.conv_wgrad(x, dy1, w1, side, after=mk)
         self._emit(grads, list(blk.parameters()))
-        return g_in
+        return (g_in, sums) if (below is not None or algebra or g_sum is not None) else g_in
 
     # ------------------------------------------------------------------ backward executor
     def _run_backward(self, rec, gpred):
@@ -308,9 +336,17 @@ class ResNet(HipBackbone):
         # otherwise wait for them anyway: both queues then end together.
         inline = ops.SideStream(dev, enabled=False)
         nblk = len(rec["blocks"])
-        for bi, brec in enumerate(reversed(rec["blocks"])):
+        blocks = rec["blocks"]
+        g_sum = None
+        for bi, brec in enumerate(reversed(blocks)):
             side.wide = nblk - bi <= self.wgrad_wide_tail
-            g = self.block_backward(brec, g, grads, side if nblk - bi > self.wgrad_main_tail else inline)
+            fi = nblk - 1 - bi                                        # forward index of this block
+            # the block below (processed next) runs its bn3 backward as algebra when it is an eligible identity block AND
+            # this block's conv1 data gradient is the one that produces its output gradient (identity shortcut here)
+            below = blocks[fi - 1] if (fi > 0 and self._bn3_algebra_ok(blocks[fi - 1])) else None
+            res = self.block_backward(brec, g, grads, side if nblk - bi > self.wgrad_main_tail else inline,
+                                      g_sum=g_sum, below=below)
+            g, g_sum = res if isinstance(res, tuple) else (res, None)
             if self._phase_boundary is not None and any(brec[0] is b for b in boundary_blks):
                 side.join()
                 self._phase_boundary(grads)

@@ -26,6 +26,7 @@ SOURCES = {
     "elementwise.hip": [],
     "optim.hip": [],
     "cfglog.hip": [],
+    "bn3alg.hip": [],
 }
 
 

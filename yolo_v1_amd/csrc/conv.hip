@@ -64,6 +64,12 @@ struct ConvArgs {
   const float* eshift = nullptr;   //   BatchNorm), out = t + ERES (bf16 residual), ReLU if erelu
   const bf16_t* ERES = nullptr;
   int ldres = 0, erelu = 0;
+  // round 3, "bn3 as algebra" (DESIGN.md section 7):
+  const bf16_t* X2 = nullptr;   // 1x1 direct launches: K-steps >= cb_split read their channels from this second source
+  int ldx2 = 0, cb_split = 0;   //   tensor (pixel stride ldx2) -- the K-concatenation [X | X2] without a copy
+  const unsigned char* OM = nullptr;   // optional OUTPUT mask [dest pixels][ldom bytes] (bit k of byte j = channel 8j+k): channels
+  int ldom = 0;                        //   whose bit is 0 are stored as zero (the ReLU mask of the block whose output gradient this is)
+  float* gsum = nullptr;               // optional [MT][Cout] per-tile column sums of the values this launch ADDED to the destination
   int M;
   int MT, NT;
   int slots = 0;       // k_conv_ps: workgroups per column tile; workgroup (slot, nt) walks the pixel tiles slot, slot+slots, ...
@@ -168,7 +174,29 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
   // shortcut-gradient operands of ALL passes up front: inside the loop every load sits behind the previous pass's store
   // (the compiler cannot prove Y and AS apart), i.e. one memory round trip per pass instead of one per tile
   uint4 as_pre[OPASSES];
-  unsigned am_pre[OPASSES];
+  unsigned am_pre[OPASSES], om_pre[OPASSES];
+  float gs[8];                                              // this thread's column sums (it keeps one 8-channel chunk: NTH % OCPR == 0)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gs[k] = 0.f;
+  if (a.OM) {
+#pragma unroll
+    for (int i = 0; i < OPASSES; ++i) {
+      const int idx = tid + i * NTH;
+      const int row = idx / OCPR, cc = idx - row * OCPR;
+      const int m = m0 + row;
+      om_pre[i] = 0xffu;
+      if (row < BM && m < a.M) {
+        size_t dp = (size_t)m;
+        if (a.os != 1) {
+          const int pq = a.P * a.Q;
+          const int n = m / pq, rem = m - n * pq;
+          const int p = rem / a.Q, q = rem - p * a.Q;
+          dp = (size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0;
+        }
+        om_pre[i] = a.OM[dp * a.ldom + ((n0 + cc * 8) >> 3)];
+      }
+    }
+  }
   if (a.AS) {
 #pragma unroll
     for (int i = 0; i < OPASSES; ++i) {
@@ -177,7 +205,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
       const int m = m0 + row;
       if (row < BM && m < a.M) {
         as_pre[i] = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + n0 + cc * 8);
-        am_pre[i] = a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)];
+        am_pre[i] = a.AM ? a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)] : 0xffu;     // no mask: AS is added as it is
       }
     }
   } else if (a.accumulate) {                 // the destination's old values, likewise (AS and accumulate are never combined)
@@ -245,8 +273,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         }
         v = make_uint4(res[0], res[1], res[2], res[3]);
       }
+      uint4 oldv = make_uint4(0u, 0u, 0u, 0u);
       if (a.accumulate) {
         const uint4 o = a.AS ? *reinterpret_cast<const uint4*>(a.Y + off) : as_pre[i];
+        oldv = o;
         const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
         const unsigned* po = reinterpret_cast<const unsigned*>(&o);
         unsigned res[4];
@@ -258,7 +288,42 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         }
         v = make_uint4(res[0], res[1], res[2], res[3]);
       }
+      if (a.OM) {                                         // zero the channels the destination block's ReLU closed
+        const unsigned mb = om_pre[i];
+        unsigned* pv = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned keep = (((mb >> (2 * k)) & 1u) ? 0x0000ffffu : 0u) | (((mb >> (2 * k + 1)) & 1u) ? 0xffff0000u : 0u);
+          pv[k] &= keep;
+        }
+      }
+      if (a.gsum) {                                       // column sums of what this launch added: stored - old (bf16 values)
+        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+        const unsigned* po = reinterpret_cast<const unsigned*>(&oldv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          gs[2 * k] += __uint_as_float(pv[k] << 16) - __uint_as_float(po[k] << 16);
+          gs[2 * k + 1] += __uint_as_float(pv[k] & 0xffff0000u) - __uint_as_float(po[k] & 0xffff0000u);
+        }
+      }
       *reinterpret_cast<uint4*>(a.Y + off) = v;
+    }
+  }
+  if (a.gsum) {
+    // fixed-order reduction over the NTH / OCPR threads that hold the same channel chunk; the epilogue tile is dead
+    static_assert(NTH % OCPR == 0, "a thread keeps its channel chunk across the store passes");
+    constexpr int RG = NTH / OCPR;
+    __syncthreads();
+    float* gred = reinterpret_cast<float*>(smem);          // [RG][BN]
+    const int cc = tid % OCPR, rg = tid / OCPR;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gred[rg * BN + cc * 8 + k] = gs[k];
+    __syncthreads();
+    if (tid < BN) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < RG; ++r) t += gred[r * BN + tid];
+      a.gsum[(size_t)mt * a.Cout + n0 + tid] = t;
     }
   }
 }
@@ -534,7 +599,12 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128
       __builtin_amdgcn_global_load_lds((glb_void*)wsrc[i], (lds_void*)(sb_ + (piece_row0 + i * RPP) * (BK * 2)), 16, 0, 0); \
       wsrc[i] += BK;                                                                                             \
     }                                                                                                            \
-    if (++ld_cb == cblocks) {                                                                                    \
+    ++ld_cb;                                                                                                     \
+    if (a.X2 && ld_cb == a.cb_split) {                   /* K-concatenation [X | X2]: direct 1x1 launches only */ \
+      _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i)                                                       \
+        asrc[i] = pix_base[i] >= 0 ? a.X2 + ((size_t)pix_base[i] * a.ldx2 + lchunk * 8) : zsrc;                  \
+    }                                                                                                            \
+    if (ld_cb == cblocks) {                                                                                      \
       ld_cb = 0;                                                                                                 \
       if (++ld_s == a.S) { ld_s = 0; ++ld_r; }                                                                   \
       YV1_SET_TAP_D();                                                                                           \
@@ -1666,6 +1736,8 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
   static int as_min_m = -1;
   if (as_min_m < 0) as_min_m = env_int("YV1_AS_DMA_MIN_M", 0);
   if (p.kind == 2 && a.AS && a.M >= as_min_m) p.kind = 1;
+  if (p.kind == 2 && (a.X2 || a.OM || a.gsum)) p.kind = 1;       // second K source / output mask / column sums: k_conv_dma only
+  if (p.kind == 0 && (a.X2 || a.OM || a.gsum)) return YV1_ERR_UNSUPPORTED;
   if (p.kind == 0) {
     const bool k64 = p.bk == 64;
     if (p.bm == 128 && p.bn == 128) return k64 ? launch<128, 128, 64, 2, 2>(a, stream) : launch<128, 128, 32, 2, 2>(a, stream);
@@ -1864,6 +1936,96 @@ extern "C" int yv1_conv2d_dgrad_add_masked_nhwc_bf16(const void* dy, const void*
   a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
   a.M = N * a.P * a.Q;
   a.AS = (const bf16_t*)g; a.ldas = ldg; a.AM = (const unsigned char*)relu_mask; a.ldam = ldmask;
+  return dispatch(a, stream);
+}
+
+// ---- "bn3 as algebra" (DESIGN.md section 7): the two convolution launches of it ------------------------------------
+// conv1's data gradient of an identity-shortcut Bottleneck as yv1_conv2d_dgrad_add_masked_nhwc_bf16, with two additions for
+// the block BELOW (whose output gradient dx is):  out_mask (nullable) -- that block's 1-bit ReLU mask: closed channels are
+// stored as zero, i.e. dx leaves this launch as the MASKED gradient gm its BatchNorm-3 backward starts from;  gsum
+// (nullable) -- [yv1_conv2d_dgrad_gsum_rows(M, Cin, Cout)][Cin] per-tile column sums of gm (its sum is bn3's dbeta).
+// relu_mask may be NULL: g is then added as it is (it already is a masked gradient).
+extern "C" int yv1_conv2d_dgrad_add_masked_out_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW,
+                                                         int lddx, int Cin, int Cout, int lddy, const void* g, int ldg,
+                                                         const void* relu_mask, int ldmask, const void* out_mask,
+                                                         int ldom, float* gsum, hipStream_t stream) {
+  yv1_cfg_reset();
+  if (!dy || !wt || !dx || !g || N <= 0) return YV1_ERR_BAD_ARG;
+  if (ldg % 8 || Cin % 8) return YV1_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.escale = a.eshift = nullptr; a.ERES = nullptr; a.ldres = 0; a.erelu = 0;
+  a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx; a.stats = nullptr;
+  a.N = N; a.IH = IH; a.IW = IW; a.ldx = lddy;
+  a.Cin = Cout; a.Cout = Cin; a.R = 1; a.S = 1;
+  a.OH = IH; a.OW = IW; a.ldy = lddx; a.accumulate = 0;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = 1; a.Kw = Cout;
+  a.P = IH; a.Q = IW; a.os = 1;
+  a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
+  a.M = N * a.P * a.Q;
+  a.AS = (const bf16_t*)g; a.ldas = ldg; a.AM = (const unsigned char*)relu_mask; a.ldam = ldmask;
+  a.OM = (const unsigned char*)out_mask; a.ldom = ldom; a.gsum = gsum;
+  return dispatch(a, stream);
+}
+
+// yv1_conv2d_dgrad_nhwc_bf16 for 1x1 / pad-0 convolutions (any stride 1 | 2) with the same two additions: the pair of data
+// gradients a PROJECTION Bottleneck ends with (conv1's, then the strided downsample convolution's scatter-accumulate) hands
+// the block below its output gradient masked, and each launch reports the column sums of what IT added (gsum rows:
+// yv1_conv2d_dgrad_gsum_rows(N*OH*OW, Cin, Cout) with OH, OW the dy grid).
+extern "C" int yv1_conv2d_dgrad_out_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin,
+                                              int Cout, int lddy, int stride, int accumulate, const void* out_mask, int ldom,
+                                              float* gsum, hipStream_t stream) {
+  yv1_cfg_reset();
+  if (!dy || !wt || !dx || N <= 0) return YV1_ERR_BAD_ARG;
+  if (stride != 1 && stride != 2) return YV1_ERR_UNSUPPORTED;
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;
+  ConvArgs a;
+  a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
+  a.escale = a.eshift = nullptr; a.ERES = nullptr; a.ldres = 0; a.erelu = 0;
+  a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx; a.stats = nullptr;
+  a.N = N; a.IH = OH; a.IW = OW; a.ldx = lddy;
+  a.Cin = Cout; a.Cout = Cin; a.R = 1; a.S = 1;
+  a.OH = IH; a.OW = IW; a.ldy = lddx; a.accumulate = accumulate;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = 1; a.Kw = Cout;
+  a.P = OH; a.Q = OW; a.os = stride;
+  a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
+  a.M = N * a.P * a.Q;
+  a.OM = (const unsigned char*)out_mask; a.ldom = ldom; a.gsum = gsum;
+  return dispatch(a, stream);
+}
+
+// partial rows of gsum for a 1x1 data gradient with M pixels, Cin (= GEMM columns) and Cout (= GEMM K): one per pixel tile
+extern "C" int yv1_conv2d_dgrad_gsum_rows(int M, int Cin, int Cout) {
+  const ConvPlan p = plan_conv(M, Cin, Cout, 1);
+  return (M + p.bm - 1) / p.bm;
+}
+
+// dx[M][Cdx] = [g | z] * wcat^T + bias:  the 1x1 stride-1 data gradient of conv3 with BatchNorm-3's backward folded into
+// its operands.  g: [N,H,W,*] bf16 (C1 channels, pixel stride ldg), z: [N,H,W,*] bf16 (C2 channels, pixel stride ldz),
+// wcat: bf16 [Cdx][C1 + C2] (K contiguous), bias: fp32 [Cdx] (one: fp32 [Cdx] of ones -- the epilogue's scale slot).
+extern "C" int yv1_conv2d_dgrad_cat_bias_nhwc_bf16(const void* g, int ldg, int C1, const void* z, int ldz, int C2,
+                                                   const void* wcat, const float* one, const float* bias, void* dx, int lddx,
+                                                   int Cdx, int N, int H, int W, hipStream_t stream) {
+  yv1_cfg_reset();
+  if (!g || !z || !wcat || !one || !bias || !dx || N <= 0) return YV1_ERR_BAD_ARG;
+  if (C1 % 64 || C2 % 64 || ldg % 8 || ldz % 8 || lddx % 8 || Cdx % 32) return YV1_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
+  a.ERES = nullptr; a.ldres = 0; a.erelu = 0;
+  a.escale = one; a.eshift = bias;                       // out = bf16(acc * 1 + bias[n])
+  a.X = (const bf16_t*)g; a.W = (const bf16_t*)wcat; a.Y = (bf16_t*)dx; a.stats = nullptr;
+  a.N = N; a.IH = H; a.IW = W; a.ldx = ldg;
+  a.Cin = C1 + C2; a.Cout = Cdx; a.R = 1; a.S = 1;
+  a.OH = H; a.OW = W; a.ldy = lddx; a.accumulate = 0;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = 1; a.Kw = C1 + C2;
+  a.P = H; a.Q = W; a.os = 1;
+  a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
+  a.M = N * H * W;
+  a.X2 = (const bf16_t*)z; a.ldx2 = ldz;
+  {
+    const ConvPlan p = plan_conv(a.M, a.Cout, a.Cin, 1);
+    if (p.kind == 0 || C1 % p.bk) return YV1_ERR_UNSUPPORTED;
+    a.cb_split = C1 / p.bk;
+  }
   return dispatch(a, stream);
 }
 

@@ -296,6 +296,129 @@ def conv_dgrad_add_masked(dy, w, dx, g, mask):
           "yv1_conv2d_dgrad_add_masked_nhwc_bf16")
 
 
+def conv_dgrad_add_masked_out(dy, w, dx, g, mask, out_mask=None, want_sum=False):
+    """conv_dgrad_add_masked with two additions for the block BELOW (dx is its output gradient): ``out_mask`` -- that block's
+    ReluMask: dx is stored already masked; ``want_sum`` -- per-tile column sums of the stored values (their sum is that
+    block's bn3 dbeta).  ``mask`` None: ``g`` is added as it is (an already masked gradient).  Returns the partial rows
+    [rows][C] (fp32) or None."""
+    if w.k != 1 or w.stride != 1 or w.pad != 0:
+        raise ValueError("conv_dgrad_add_masked_out: 1x1 stride-1 convolution only")
+    if (g.N, g.H, g.W, g.C) != (dx.N, dx.H, dx.W, dx.C):
+        raise ValueError("conv_dgrad_add_masked_out: g must have dx's geometry")
+    dev = dy.t.device
+    L = lib()
+    gsum = None
+    if want_sum:
+        rows = L.yv1_conv2d_dgrad_gsum_rows(dx.npix, w.Ipad, w.Opad)
+        gsum = _f32(rows * dx.C, dev).view(rows, dx.C)
+    check(L.yv1_conv2d_dgrad_add_masked_out_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld,
+                                                      g.p, g.ld, mask.p if mask is not None else None,
+                                                      mask.ld if mask is not None else 0,
+                                                      out_mask.p if out_mask is not None else None,
+                                                      out_mask.ld if out_mask is not None else 0, ptr(gsum), stream_ptr(dev)),
+          "yv1_conv2d_dgrad_add_masked_out_nhwc_bf16")
+    return gsum
+
+
+def conv_dgrad_out(dy, w, dx, accumulate, out_mask, want_sum=True):
+    """conv_dgrad for a 1x1 pad-0 convolution (stride 1 | 2) whose result is the output gradient of the block below: stored
+    masked by that block's ReluMask, with the per-tile column sums of what this launch added (see
+    conv_dgrad_add_masked_out).  Returns the partial rows or None."""
+    if w.k != 1 or w.pad != 0:
+        raise ValueError("conv_dgrad_out: 1x1 pad-0 convolution only")
+    dev = dy.t.device
+    L = lib()
+    gsum = None
+    if want_sum:
+        rows = L.yv1_conv2d_dgrad_gsum_rows(dy.npix, w.Ipad, w.Opad)
+        gsum = _f32(rows * dx.C, dev).view(rows, dx.C)
+    check(L.yv1_conv2d_dgrad_out_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld, w.stride,
+                                           1 if accumulate else 0, out_mask.p if out_mask is not None else None,
+                                           out_mask.ld if out_mask is not None else 0, ptr(gsum), stream_ptr(dev)),
+          "yv1_conv2d_dgrad_out_nhwc_bf16")
+    return gsum
+
+
+def wgrad_raw(x, dy, shared=False):
+    """fp32 [Cdy][1][Cx] = dy^T x over all pixels (the 1x1 weight-gradient GEMM on arbitrary operands: T = gm^T z2 and
+    G = z2^T z2 of the bn3 algebra).  ``shared``: the split-K width for launches that run beside another stream."""
+    dev = x.t.device
+    L = lib()
+    out = torch.empty((dy.C, 1, x.C), dtype=torch.float32, device=dev)
+    wsb = L.yv1_conv2d_wgrad_workspace_bytes(x.N, dy.H, dy.W, x.C, dy.C, 1)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    fn = L.yv1_conv2d_wgrad_shared_nhwc_bf16 if shared else L.yv1_conv2d_wgrad_nhwc_bf16
+    check(fn(x.p, dy.p, ptr(out), x.N, x.H, x.W, x.ld, x.C, dy.C, dy.ld, 1, 1, 0, ptr(ws), wsb, stream_ptr(dev)),
+          "yv1_conv2d_wgrad_nhwc_bf16")
+    return out, ws
+
+
+_ONES = {}
+
+
+def _ones(n, device):
+    key = (torch.device(device).index, n)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+import os as _os2
+# "bn3's backward as algebra" (DESIGN.md section 7, csrc/bn3alg.hip): identity-shortcut Bottlenecks up to this many planes
+# run their BatchNorm-3 backward inside the 1x1 GEMMs next to it (0 = off)
+# Measured per stage (interleaved A/B of the step): off 2938-2946 img/s, layer1 only (64) 2957, layer1-2 (128) 2974-2975,
+# layer1-3 (256) 2926-2930 -- at 28x28 the two passes it removes (34 + 57 us) no longer cover T on the main stream, the
+# 256 x 256 x 1024 operand build and the 25 % longer data gradient.
+BN3_ALGEBRA_MAX_P = int(_os2.environ.get("YV1_BN3_ALGEBRA", "128"))
+
+
+def bn3_algebra_backward(gm, gsum, z2, w3, st3, bn3, conv3_param, dz2, side):
+    """BatchNorm-3 + conv3 backward of an identity Bottleneck from the MASKED block-output gradient ``gm`` (Act, 4p channels)
+    and its per-tile column sums ``gsum``: returns (dgamma, dbeta, dW3 view); writes dz2.  The stand-alone reduce / apply
+    passes over gm and y3 do not run and dy3 is never formed (csrc/bn3alg.hip has the algebra)."""
+    dev = gm.t.device
+    L = lib()
+    s = stream_ptr(dev)
+    p, C4 = z2.C, gm.C
+    M = gm.npix
+    # T = gm^T z2 on the MAIN stream: the coefficients, and with them the data gradient, wait for it
+    T, ws_t = wgrad_raw(z2, gm, shared=False)
+    rows = gsum.shape[0]
+    if rows > 64:
+        RB = (rows + 31) // 32
+        r2 = (rows + RB - 1) // RB
+        gs2 = _f32(r2 * C4, dev)
+        check(L.yv1_reduce_rows(ptr(gsum), ptr(gs2), rows, C4, RB, s), "yv1_reduce_rows")
+        gsum, rows = gs2, r2
+    kk = torch.empty((3, C4), dtype=torch.float32, device=dev)        # k1, k2, k3*invstd
+    if _ARENA[0] is not None:
+        dgam, dbet = _grad_buf(bn3.weight, (C4,)), _grad_buf(bn3.bias, (C4,))
+    else:
+        gb = torch.empty((2, C4), dtype=torch.float32, device=dev)
+        dgam, dbet = gb[0], gb[1]
+    check(L.yv1_bn3_coeffs(ptr(gsum), rows, ptr(T), ptr(w3.fwd), p, C4, ptr(st3.mean), ptr(st3.invstd), ptr(bn3.weight),
+                           float(M), ptr(dgam), ptr(dbet), ptr(kk[0]), ptr(kk[1]), ptr(kk[2]), s), "yv1_bn3_coeffs")
+    wcat = torch.empty((p, C4 + p), dtype=torch.bfloat16, device=dev)
+    bias = torch.empty(p, dtype=torch.float32, device=dev)
+    check(L.yv1_bn3_build(ptr(w3.fwd), p, C4, ptr(kk[0]), ptr(kk[1]), ptr(kk[2]), ptr(st3.mean), ptr(wcat), ptr(bias), s),
+          "yv1_bn3_build")
+    mk = side.mark()
+    check(L.yv1_conv2d_dgrad_cat_bias_nhwc_bf16(gm.p, gm.ld, C4, z2.p, z2.ld, p, ptr(wcat), ptr(_ones(p, dev)), ptr(bias),
+                                                dz2.p, dz2.ld, p, gm.N, gm.H, gm.W, s), "yv1_conv2d_dgrad_cat_bias_nhwc_bf16")
+    dW = _grad_buf(conv3_param, (C4, 1, p))
+
+    def weight_side():
+        overl = side.side is not None and not getattr(side, "wide", False)
+        G, ws_g = wgrad_raw(z2, z2, shared=overl)
+        szp = bn_stats(z2)
+        check(L.yv1_bn3_dw(ptr(T), ptr(G), ptr(szp), szp.shape[0], ptr(w3.fwd), p, C4, ptr(kk[0]), ptr(kk[1]), ptr(kk[2]),
+                           ptr(st3.mean), ptr(dW), stream_ptr(dev)), "yv1_bn3_dw")
+        return G, ws_g, szp
+    keep = side.run(weight_side, z2.t, T, ws_t, kk, wcat, bias, dW, after=mk)
+    side.keep.append(keep)
+    return dgam, dbet, dW.view(C4, 1, 1, p).permute(0, 3, 1, 2)
+
+
 class SideStream:
     """Runs leaf work (weight gradients: nothing else in the backward consumes them) on a second HIP stream so it
     overlaps with the dgrad / BatchNorm chain on the main stream -- eagerly and inside a captured hipGraph
