@@ -239,7 +239,10 @@ int yv1_conv2d_dgrad_out_nhwc_bf16(const void* dy, const void* wt, void* dx, int
 int yv1_conv2d_dgrad_gsum_rows(int M, int Cin, int Cout);
 int yv1_conv2d_dgrad_cat_bias_nhwc_bf16(const void* g, int ldg, int C1, const void* z, int ldz, int C2, const void* wcat,
                                         const float* one, const float* bias, void* dx, int lddx, int Cdx, int N, int H, int W,
-                                        yv1_stream_t stream);
+                                        int stride, int accumulate, const void* out_mask, int ldom, float* gsum,
+                                        yv1_stream_t stream);   /* gsum rows: yv1_conv2d_dgrad_gsum_rows(N*H*W, Cdx, C1+C2) */
+/* x [N,H,W,*] -> y [N,H/2,W/2,*]: the pixels a stride-2 1x1 convolution reads, made dense (bf16, C % 8 == 0) */
+int yv1_subsample2_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, yv1_stream_t stream);
 int yv1_bn3_coeffs(const float* gsum, int rows, const float* T, const void* w3, int p, int C4, const float* mean,
                    const float* invstd, const float* gamma, float count, float* dgamma, float* dbeta, float* k1, float* k2,
                    float* k3is, yv1_stream_t stream);

@@ -56,7 +56,9 @@ SIGNATURES = {
                                                         c_i, c_p, c_p]),
     "yv1_conv2d_dgrad_out_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "yv1_conv2d_dgrad_gsum_rows": (c_i, [c_i, c_i, c_i]),
-    "yv1_conv2d_dgrad_cat_bias_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "yv1_conv2d_dgrad_cat_bias_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                                  c_p, c_i, c_p, c_p]),
+    "yv1_subsample2_nhwc_bf16": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     # bn3alg.hip
     "yv1_bn3_coeffs": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yv1_bn3_build": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

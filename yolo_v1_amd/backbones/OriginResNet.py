@@ -229,8 +229,8 @@ class ResNet(HipBackbone):
         """Identity-shortcut Bottleneck whose BatchNorm-3 backward can run as algebra (ops.bn3_algebra_backward)."""
         blk, x, y1 = brec[0], brec[1], brec[2]
         p = blk.conv1.out_channels
-        return (brec[10] is None and brec[13] is not None and ops.BN3_ALGEBRA_MAX_P > 0 and p % 64 == 0 and
-                p <= ops.BN3_ALGEBRA_MAX_P)
+        return (brec[13] is not None and ops.BN3_ALGEBRA_MAX_P > 0 and p % 64 == 0 and p <= ops.BN3_ALGEBRA_MAX_P and
+                (brec[10] is None or (ops.BN3_ALGEBRA_PROJ and x.C % 64 == 0)))
 
     def block_backward(self, brec, g, grads, side, g_sum=None, below=None):
         """Backward of one Bottleneck: ``g`` is the gradient of the block output; fills ``grads`` and returns the gradient of
@@ -248,6 +248,9 @@ class ResNet(HipBackbone):
             # bn3's reduce / finalize / apply passes and conv3's ordinary dgrad + wgrad, as four GEMM-side steps
             (grads[blk.bn3.weight], grads[blk.bn3.bias], grads[blk.conv3.weight]) = ops.bn3_algebra_backward(
                 g, g_sum, z2, w3, s3, blk.bn3, blk.conv3.weight, dz2, side)
+            if yd is not None:
+                wd = self.cw(blk.downsample[0])
+                bnd = blk.downsample[1]
         else:
             dy3 = ops.new_act(N, y3.H, y3.W, y3.C, dev)
             if yd is not None:
@@ -287,7 +290,18 @@ class ResNet(HipBackbone):
         grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
         mk = side.mark()
         sums = None
-        if yd is not None and below is not None:
+        if yd is not None and algebra:
+            # projection block under the algebra: conv1's data gradient first, then the downsample BatchNorm + convolution
+            # backward as algebra on the same masked gradient, scatter-accumulated into g_in (x at the strided pixels, dense)
+            bmask = below[13] if below is not None else None
+            s_a = ops.conv_dgrad_out(dy1, w1, g_in, False, bmask) if below is not None else ops.conv_dgrad(dy1, w1, g_in)
+            xs = x if wd.stride == 1 else ops.subsample2(x)
+            res = ops.bn3_algebra_backward(g, g_sum, xs, wd, sd, bnd, blk.downsample[0].weight, g_in, side, stride=wd.stride,
+                                           accumulate=True, out_mask=bmask)
+            grads[bnd.weight], grads[bnd.bias], grads[blk.downsample[0].weight] = res[0], res[1], res[2]
+            if below is not None:
+                sums = torch.cat([s_a, res[3]], 0)
+        elif yd is not None and below is not None:
             # the block below runs its bn3 backward as algebra: both data gradients store its output gradient masked by ITS
             # ReLU mask and report the column sums of what they added
             s_a = ops.conv_dgrad_out(dy1, w1, g_in, False, below[13])

@@ -2004,10 +2004,14 @@ extern "C" int yv1_conv2d_dgrad_gsum_rows(int M, int Cin, int Cout) {
 // wcat: bf16 [Cdx][C1 + C2] (K contiguous), bias: fp32 [Cdx] (one: fp32 [Cdx] of ones -- the epilogue's scale slot).
 extern "C" int yv1_conv2d_dgrad_cat_bias_nhwc_bf16(const void* g, int ldg, int C1, const void* z, int ldz, int C2,
                                                    const void* wcat, const float* one, const float* bias, void* dx, int lddx,
-                                                   int Cdx, int N, int H, int W, hipStream_t stream) {
+                                                   int Cdx, int N, int H, int W, int stride, int accumulate,
+                                                   const void* out_mask, int ldom, float* gsum, hipStream_t stream) {
+  // g, z: [N,H,W,*] (the GEMM pixels); dx: [N, H*stride', W*stride', *] with pixel (h, w) of the GEMM stored at
+  // (h*stride, w*stride) -- stride 2: the projection shortcut's scatter (dx spatial size = IH x IW given by H*stride... the
+  // caller passes the GEMM grid H x W and dx is (H-1)*stride+1 .. rounded up to even: IH = H*stride for stride 2)
   yv1_cfg_reset();
   if (!g || !z || !wcat || !one || !bias || !dx || N <= 0) return YV1_ERR_BAD_ARG;
-  if (C1 % 64 || C2 % 64 || ldg % 8 || ldz % 8 || lddx % 8 || Cdx % 32) return YV1_ERR_UNSUPPORTED;
+  if (C1 % 64 || C2 % 64 || ldg % 8 || ldz % 8 || lddx % 8 || Cdx % 32 || (stride != 1 && stride != 2)) return YV1_ERR_UNSUPPORTED;
   ConvArgs a;
   a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
   a.ERES = nullptr; a.ldres = 0; a.erelu = 0;
@@ -2015,12 +2019,13 @@ extern "C" int yv1_conv2d_dgrad_cat_bias_nhwc_bf16(const void* g, int ldg, int C
   a.X = (const bf16_t*)g; a.W = (const bf16_t*)wcat; a.Y = (bf16_t*)dx; a.stats = nullptr;
   a.N = N; a.IH = H; a.IW = W; a.ldx = ldg;
   a.Cin = C1 + C2; a.Cout = Cdx; a.R = 1; a.S = 1;
-  a.OH = H; a.OW = W; a.ldy = lddx; a.accumulate = 0;
+  a.OH = H * stride; a.OW = W * stride; a.ldy = lddx; a.accumulate = accumulate;
   a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = 1; a.Kw = C1 + C2;
-  a.P = H; a.Q = W; a.os = 1;
+  a.P = H; a.Q = W; a.os = stride;
   a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
   a.M = N * H * W;
   a.X2 = (const bf16_t*)z; a.ldx2 = ldz;
+  a.OM = (const unsigned char*)out_mask; a.ldom = ldom; a.gsum = gsum;      // as yv1_conv2d_dgrad_out_nhwc_bf16
   {
     const ConvPlan p = plan_conv(a.M, a.Cout, a.Cin, 1);
     if (p.kind == 0 || C1 % p.bk) return YV1_ERR_UNSUPPORTED;

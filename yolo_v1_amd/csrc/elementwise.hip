@@ -1158,6 +1158,24 @@ __global__ void __launch_bounds__(256, 4) k_bn_bwd_apply_pool2(BwdArgs a) {
   }
 }
 
+// x [N,H,W,*] -> y [N,H/2,W/2,*]: the pixels (2h, 2w) a stride-2 1x1 convolution reads, made dense ("bn3 as algebra" for a
+// strided projection shortcut needs x_s as a GEMM operand)
+__global__ void __launch_bounds__(256) k_subsample2(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int N,
+                                                    int H, int W, int C) {
+  const int OH = H >> 1, OW = W >> 1, CH = C >> 3;
+  const long long total = (long long)N * OH * OW * CH;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % CH);
+    long long t = i / CH;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const size_t src = ((size_t)(n * H + 2 * oh) * W + 2 * ow) * ldx + cc * 8;
+    const size_t dst = ((size_t)(n * OH + oh) * OW + ow) * ldy + cc * 8;
+    *reinterpret_cast<u32x4*>(y + dst) = *reinterpret_cast<const u32x4*>(x + src);
+  }
+}
+
 // ------------------------------------------------------------------ max pool 3x3 / stride 2 / pad 1
 __global__ void __launch_bounds__(256) k_maxpool_fwd(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
                                                      unsigned char* __restrict__ idx, int N, int H, int W, int C) {
@@ -2008,6 +2026,15 @@ extern "C" int yv1_bn_bwd_apply_dual(const void* dz, int lddz, const void* z, in
   const int blocks = fixed_chunk_grid(npix * (C / 8), C / 8, &fixed);
   if (!fixed) return YV1_ERR_UNSUPPORTED;               // every ResNet width qualifies (C/8 a power of two)
   hipLaunchKernelGGL(k_bn_bwd_apply_dual, dim3(blocks), dim3(256), 0, stream, a);
+  YV1_LAUNCH_CHECK();
+  return YV1_OK;
+}
+
+extern "C" int yv1_subsample2_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C,
+                                        hipStream_t stream) {
+  if (!x || !y || N <= 0 || (H & 1) || (W & 1) || C % 8 || ldx % 8 || ldy % 8) return YV1_ERR_BAD_ARG;
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(k_subsample2, dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, H, W, C);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }

@@ -370,26 +370,41 @@ import os as _os2
 # layer1-3 (256) 2926-2930 -- at 28x28 the two passes it removes (34 + 57 us) no longer cover T on the main stream, the
 # 256 x 256 x 1024 operand build and the 25 % longer data gradient.
 BN3_ALGEBRA_MAX_P = int(_os2.environ.get("YV1_BN3_ALGEBRA", "128"))
+# projection Bottlenecks too (bn3 and the downsample BatchNorm, both on the same masked gradient).  Built, parity-tested
+# (3.4e-3 against the dual passes) and measured LEVEL (3038-3051 vs 3036-3039 img/s): the dual passes already share their
+# reads of the gradient and the mask, and the algebra puts two T GEMMs in front of the data gradients.  Off by default.
+BN3_ALGEBRA_PROJ = _os2.environ.get("YV1_BN3_ALGEBRA_PROJ", "0") == "1"
 
 
-def bn3_algebra_backward(gm, gsum, z2, w3, st3, bn3, conv3_param, dz2, side):
-    """BatchNorm-3 + conv3 backward of an identity Bottleneck from the MASKED block-output gradient ``gm`` (Act, 4p channels)
-    and its per-tile column sums ``gsum``: returns (dgamma, dbeta, dW3 view); writes dz2.  The stand-alone reduce / apply
-    passes over gm and y3 do not run and dy3 is never formed (csrc/bn3alg.hip has the algebra)."""
+def _gsum_rows_le32(gsum, dev):
+    """Pre-reduce the per-tile column sums to at most 32 rows (coalesced): the coefficient kernel reads them per channel."""
+    rows, C = gsum.shape
+    if rows <= 64:
+        return gsum, rows
+    RB = (rows + 31) // 32
+    r2 = (rows + RB - 1) // RB
+    out = _f32(r2 * C, dev)
+    check(lib().yv1_reduce_rows(ptr(gsum), ptr(out), rows, C, RB, stream_ptr(dev)), "yv1_reduce_rows")
+    return out.view(r2, C), r2
+
+
+def bn3_algebra_backward(gm, gsum, z2, w3, st3, bn3, conv3_param, dz2, side, stride=1, accumulate=False, out_mask=None):
+    """BatchNorm + pointwise-convolution backward as algebra (csrc/bn3alg.hip) from the MASKED block-output gradient ``gm``
+    (Act, 4p channels) and its per-tile column sums ``gsum``.  ``z2``: the convolution's DENSE input [N,h,w,p] (conv3: z2;
+    a projection shortcut: the block input at the pixels the strided convolution reads), ``w3`` / ``st3`` / ``bn3``: the
+    convolution's ConvWeights and its BatchNorm; ``dz2``: where the input gradient goes (``stride`` 2 + ``accumulate``: the
+    shortcut's scatter-accumulate into the block-input gradient; ``out_mask``: dz2 is the output gradient of the block below,
+    stored masked by its ReluMask, and a fourth return value holds the column sums of what was added).  Returns (dgamma,
+    dbeta, dW view[, sums]).  The stand-alone reduce /
+    apply passes over gm and the convolution output do not run; the output gradient of the convolution is never formed."""
     dev = gm.t.device
     L = lib()
     s = stream_ptr(dev)
     p, C4 = z2.C, gm.C
     M = gm.npix
-    # T = gm^T z2 on the MAIN stream: the coefficients, and with them the data gradient, wait for it
+    # T = gm^T z on the MAIN stream: the coefficients, and with them the data gradient, wait for it
     T, ws_t = wgrad_raw(z2, gm, shared=False)
-    rows = gsum.shape[0]
-    if rows > 64:
-        RB = (rows + 31) // 32
-        r2 = (rows + RB - 1) // RB
-        gs2 = _f32(r2 * C4, dev)
-        check(L.yv1_reduce_rows(ptr(gsum), ptr(gs2), rows, C4, RB, s), "yv1_reduce_rows")
-        gsum, rows = gs2, r2
+    gsum, rows = _gsum_rows_le32(gsum, dev)
     kk = torch.empty((3, C4), dtype=torch.float32, device=dev)        # k1, k2, k3*invstd
     if _ARENA[0] is not None:
         dgam, dbet = _grad_buf(bn3.weight, (C4,)), _grad_buf(bn3.bias, (C4,))
@@ -403,8 +418,15 @@ def bn3_algebra_backward(gm, gsum, z2, w3, st3, bn3, conv3_param, dz2, side):
     check(L.yv1_bn3_build(ptr(w3.fwd), p, C4, ptr(kk[0]), ptr(kk[1]), ptr(kk[2]), ptr(st3.mean), ptr(wcat), ptr(bias), s),
           "yv1_bn3_build")
     mk = side.mark()
+    osum = None
+    if out_mask is not None:
+        orows = L.yv1_conv2d_dgrad_gsum_rows(gm.npix, p, C4 + p)
+        osum = _f32(orows * p, dev).view(orows, p)
     check(L.yv1_conv2d_dgrad_cat_bias_nhwc_bf16(gm.p, gm.ld, C4, z2.p, z2.ld, p, ptr(wcat), ptr(_ones(p, dev)), ptr(bias),
-                                                dz2.p, dz2.ld, p, gm.N, gm.H, gm.W, s), "yv1_conv2d_dgrad_cat_bias_nhwc_bf16")
+                                                dz2.p, dz2.ld, p, gm.N, gm.H, gm.W, stride, 1 if accumulate else 0,
+                                                out_mask.p if out_mask is not None else None,
+                                                out_mask.ld if out_mask is not None else 0, ptr(osum), s),
+          "yv1_conv2d_dgrad_cat_bias_nhwc_bf16")
     dW = _grad_buf(conv3_param, (C4, 1, p))
 
     def weight_side():
@@ -416,7 +438,17 @@ def bn3_algebra_backward(gm, gsum, z2, w3, st3, bn3, conv3_param, dz2, side):
         return G, ws_g, szp
     keep = side.run(weight_side, z2.t, T, ws_t, kk, wcat, bias, dW, after=mk)
     side.keep.append(keep)
+    if out_mask is not None:
+        return dgam, dbet, dW.view(C4, 1, 1, p).permute(0, 3, 1, 2), osum
     return dgam, dbet, dW.view(C4, 1, 1, p).permute(0, 3, 1, 2)
+
+
+def subsample2(x):
+    """The pixels (2h, 2w) of an NHWC bf16 activation, dense: what a stride-2 1x1 convolution reads."""
+    y = new_act(x.N, x.H // 2, x.W // 2, x.C, x.t.device)
+    check(lib().yv1_subsample2_nhwc_bf16(x.p, x.ld, y.p, y.ld, x.N, x.H, x.W, x.C, stream_ptr(x.t.device)),
+          "yv1_subsample2_nhwc_bf16")
+    return y
 
 
 class SideStream:
