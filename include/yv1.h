@@ -219,16 +219,6 @@ int yv1_bn_bwd_finalize_apply_dual(const float* partials, const float* partials2
                                    const float* mean, const float* invstd, void* dy, int lddy, const void* y2, int ldy2,
                                    const float* mean2, const float* invstd2, void* dy2, int lddy2, long long npix, int C,
                                    int mask_mode, unsigned* sync, unsigned* fault, yv1_stream_t stream);
-/* Two-pass forward of a pointwise convolution whose raw output is never stored (round 3: conv3 of the Bottlenecks whose
- * BatchNorm-3 backward runs as algebra -- nothing reads y3 any more): pass 1 writes only the BatchNorm statistic partials,
- * pass 2 (after yv1_bn_finalize) recomputes the GEMM with BatchNorm, residual add and ReLU in its epilogue and writes the
- * block output + its 1-bit ReLU mask.  -7 p-wide tensor passes per block for one extra small-K GEMM. */
-int yv1_conv2d_fwd_stats_only_nhwc_bf16(const void* x, const void* w, int N, int IH, int IW, int ldx, int Cin, int Cout, int k,
-                                        int stride, int pad, float* stats, yv1_stream_t stream);
-int yv1_conv2d_fwd_bn_act_mask_nhwc_bf16(const void* x, const void* w, void* y, int N, int IH, int IW, int ldx, int Cin,
-                                         int Cout, int ldy, int k, int stride, int pad, const float* scale, const float* shift,
-                                         const void* residual, int ldres, int relu, void* relu_mask, int ldmask,
-                                         yv1_stream_t stream);
 /* "bn3's backward as algebra" (round 3).  An identity-shortcut Bottleneck ends
  * out = relu(bn3(conv3(z2)) + x) (OriginResNet.py:97-105); conv3 is pointwise, so BatchNorm-3's backward commutes with it:
  * from the MASKED output gradient gm, T = gm^T z2 (yv1_conv2d_wgrad_nhwc_bf16 fed gm), G = z2^T z2 and column sums,

@@ -218,9 +218,8 @@ def test_training_step_with_and_without_the_algebra(maxp, proj, rel_tol, cos_tol
     from yolo_v1_amd.v1Loss import YOLOLossV1
     images, target = synthetic_batch(8, 4, hw=256, device=DEV)
     runs = []
-    default = (ops.BN3_ALGEBRA_MAX_P, ops.BN3_ALGEBRA_PROJ, ops.BN3_TWO_PASS_FWD)
+    default = (ops.BN3_ALGEBRA_MAX_P, ops.BN3_ALGEBRA_PROJ)
     try:
-        ops.BN3_TWO_PASS_FWD = False                # the stored-y3 forward: both backward forms start from the SAME forward
         for mp in (0, maxp, maxp):
             ops.BN3_ALGEBRA_MAX_P, ops.BN3_ALGEBRA_PROJ = mp, proj
             torch.manual_seed(3)
@@ -235,7 +234,7 @@ def test_training_step_with_and_without_the_algebra(maxp, proj, rel_tol, cos_tol
             torch.cuda.synchronize()
             runs.append((float(loss.item()), {n: q.grad.detach().clone() for n, q in net.named_parameters()}))
     finally:
-        ops.BN3_ALGEBRA_MAX_P, ops.BN3_ALGEBRA_PROJ, ops.BN3_TWO_PASS_FWD = default
+        ops.BN3_ALGEBRA_MAX_P, ops.BN3_ALGEBRA_PROJ = default
     (l0, g0), (l1, g1), (l2, g2) = runs
     assert l0 == l1 == l2                                                   # the forward is untouched
     for n in g1:
@@ -254,47 +253,3 @@ def test_training_step_with_and_without_the_algebra(maxp, proj, rel_tol, cos_tol
         assert r <= rel_tol and c >= cos_tol, (n, r, c)
     print("\nalgebra (max planes %d, projection blocks %s) vs passes: worst parameter-gradient rel-L2 %.2e (%s)" % (
         maxp, proj, worst[1], worst[0]))
-
-
-@pytest.mark.parametrize("N,H,p", [(8, 56, 64), (16, 28, 128)])
-def test_two_pass_conv3_forward_matches_the_stored_y3_forward(N, H, p):
-    """conv3 -> bn3 -> (+x) -> relu of an identity Bottleneck (OriginResNet.py:97-105) as statistics-only pass + fused
-    epilogue pass, against conv (y3 stored) + bn_finalize + bn_apply.  Statistics: same accumulators, same partial rows ->
-    bit-identical BNState and running statistics.  Output: the two paths round differently ONCE (bf16(acc) * scale + shift vs
-    bf16(acc * scale + shift)): within one bf16 ulp of the pre-add value; the masks agree wherever the output is not within
-    that ulp of zero."""
-    from yolo_v1_amd import ops
-    C4 = 4 * p
-    g = torch.Generator().manual_seed(5 * p + H)
-    M = N * H * H
-    z2 = ops.Act((torch.relu(torch.randn(N, H, H, p, generator=g) * 0.8 + 0.2)).to(torch.bfloat16).to(DEV))
-    x = ops.Act(torch.randn(N, H, H, C4, generator=g).to(torch.bfloat16).to(DEV))
-    conv3 = torch.nn.Parameter((torch.randn(C4, p, 1, 1, generator=g) * (2.0 / p) ** 0.5).to(DEV)
-                               .contiguous(memory_format=torch.channels_last))
-    w3 = ops.ConvWeights(conv3, 1, 1, 0)
-    w3.refresh()
-    def mk_bn():
-        bn = torch.nn.BatchNorm2d(C4).to(DEV)
-        with torch.no_grad():
-            bn.weight.copy_(torch.rand(C4, generator=torch.Generator().manual_seed(1)).to(DEV) + 0.5)
-            bn.bias.copy_(torch.randn(C4, generator=torch.Generator().manual_seed(2)).to(DEV) * 0.3)
-        return bn
-    bn_a, bn_b = mk_bn(), mk_bn()
-    y3 = ops.new_act(N, H, H, C4, DEV)
-    st_a = ops.bn_finalize(ops.conv_fwd(z2, w3, y3, True), M, bn_a)
-    out_a = ops.new_act(N, H, H, C4, DEV)
-    mask_a = ops.bn_apply(y3, st_a, out_a, relu=True, residual=x, want_mask=True)
-    st_b = ops.bn_finalize(ops.conv_fwd_stats_only(z2, w3, M), M, bn_b)
-    out_b = ops.new_act(N, H, H, C4, DEV)
-    mask_b = ops.conv_fwd_bn_act_mask(z2, w3, out_b, st_b, relu=True, residual=x)
-    torch.cuda.synchronize()
-    assert torch.equal(st_a.buf, st_b.buf)
-    assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
-    a, b = out_a.t.float(), out_b.t.float()
-    pre = (y3.t.float() * st_a.scale + st_a.shift).abs()                  # magnitude of the value that is rounded differently
-    ulp = pre * 2.0 ** -7 + x.t.float().abs() * 2.0 ** -8 + 1e-6
-    assert bool(((a - b).abs() <= ulp).all()), float(((a - b).abs() / ulp).max())
-    assert torch.equal(_bits(mask_b, M, C4).view(N, H, H, C4), out_b.t > 0)   # the mask is the sign of what was stored
-    differ = _bits(mask_a, M, C4) != _bits(mask_b, M, C4)
-    assert float(differ.float().mean()) < 5e-3
-    assert bool((torch.maximum(a, b).view(M, C4)[differ] <= ulp.view(M, C4)[differ]).all())

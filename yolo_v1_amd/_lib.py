@@ -63,9 +63,6 @@ SIGNATURES = {
     "yv1_bn3_coeffs": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yv1_bn3_build": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yv1_bn3_dw": (c_i, [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "yv1_conv2d_fwd_stats_only_nhwc_bf16": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "yv1_conv2d_fwd_bn_act_mask_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
-                                                   c_i, c_i, c_p, c_i, c_p]),
     "yv1_conv2d_stats_rows": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "yv1_pack_input_nhwc4": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     # wgrad.hip

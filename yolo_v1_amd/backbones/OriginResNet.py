@@ -111,7 +111,7 @@ class ResNet(HipBackbone):
         ops.conv_fwd(x, wh, yh, False)
         return ops.head_fwd(yh, ops.bn_eval_state(self.bn_end), self.out_channels)
 
-    def block_forward(self, blk, x, x8, norm, conv, q8, save, norm_apply=None, two_pass=False):
+    def block_forward(self, blk, x, x8, norm, conv, q8, save, norm_apply=None):
         """One Bottleneck (OriginResNet.py:87-107).  ``norm(stats, count, bn)`` -> BNState, ``conv(x, x8, ConvParam, y)``
         -> statistic partials, ``q8(act)`` -> e4m3 twin or None; ``norm_apply`` (training, ops.BN_FUSED): BatchNorm finalize
         and apply in ONE launch -- same signature family as ops.bn_finalize_apply.  Returns (out, out8, record for
@@ -138,18 +138,11 @@ class ResNet(HipBackbone):
         else:
             s2 = norm(p2, y2.npix, blk.bn2)
             ops.bn_apply(y2, s2, z2, relu=True, z8=z2_8)
+        y3 = ops.new_act(N, h2, w2_, cout, dev)
+        p3 = conv(z2, z2_8, blk.conv3, y3)
         out = ops.new_act(N, h2, w2_, cout, dev)
         out8 = q8(out)
         yd = sd = None
-        if two_pass and blk.downsample is None:
-            # conv3 in two passes (ops.conv_fwd_bn_act_mask): its raw output y3 is never stored -- the BatchNorm-3 backward of
-            # this block runs as algebra and does not read it
-            w3 = self.cw(blk.conv3)
-            s3 = norm(ops.conv_fwd_stats_only(z2, w3, out.npix), out.npix, blk.bn3)
-            omask = ops.conv_fwd_bn_act_mask(z2, w3, out, s3, relu=True, residual=x, want_mask=save)
-            return out, out8, (blk, x, y1, s1, z1, y2, s2, z2, None, s3, None, None, out, omask)
-        y3 = ops.new_act(N, h2, w2_, cout, dev)
-        p3 = conv(z2, z2_8, blk.conv3, y3)
         if blk.downsample is not None:
             yd = ops.new_act(N, h2, w2_, cout, dev)
             pd = conv(x, x8, blk.downsample[0], yd)
@@ -217,9 +210,8 @@ class ResNet(HipBackbone):
         x8 = ops.quantize_fp8(x) if f8 else None
         rec["stem"] = (xp, y0, s0, None, H, W, pidx)
 
-        alg = self._algebra_block_ids() if (train and ops.BN3_TWO_PASS_FWD and not f8) else ()
         for blk in self._blocks():
-            x, x8, brec = self.block_forward(blk, x, x8, norm, conv, q8, save, fused, two_pass=id(blk) in alg)
+            x, x8, brec = self.block_forward(blk, x, x8, norm, conv, q8, save, fused)
             if save:
                 rec["blocks"].append(brec)
 
@@ -233,17 +225,12 @@ class ResNet(HipBackbone):
             self._bump_counters(bns)
         return pred, (rec if save else None)
 
-    def _algebra_block_ids(self):
-        """ids of the Bottleneck modules whose BatchNorm-3 backward runs as algebra: decided from the architecture alone
-        (planes, shortcut kind, a block above that can hand over the masked gradient), so the forward can rely on it."""
-        blks = list(self._blocks())
-        out = set()
-        for fi, blk in enumerate(blks[:-1]):                       # the last block's gradient comes from the head
-            p = blk.conv1.out_channels
-            ok = ops.BN3_ALGEBRA_MAX_P > 0 and p % 64 == 0 and p <= ops.BN3_ALGEBRA_MAX_P
-            if ok and (blk.downsample is None or (ops.BN3_ALGEBRA_PROJ and blk.conv1.in_channels % 64 == 0)):
-                out.add(id(blk))
-        return out
+    def _bn3_algebra_ok(self, brec):
+        """Identity-shortcut Bottleneck whose BatchNorm-3 backward can run as algebra (ops.bn3_algebra_backward)."""
+        blk, x, y1 = brec[0], brec[1], brec[2]
+        p = blk.conv1.out_channels
+        return (brec[13] is not None and ops.BN3_ALGEBRA_MAX_P > 0 and p % 64 == 0 and p <= ops.BN3_ALGEBRA_MAX_P and
+                (brec[10] is None or (ops.BN3_ALGEBRA_PROJ and x.C % 64 == 0)))
 
     def block_backward(self, brec, g, grads, side, g_sum=None, below=None):
         """Backward of one Bottleneck: ``g`` is the gradient of the block output; fills ``grads`` and returns the gradient of
@@ -257,9 +244,6 @@ class ResNet(HipBackbone):
         g_in = ops.new_act(N, x.H, x.W, x.C, dev)
         algebra = g_sum is not None
         dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
-        if y3 is None and not algebra:
-            raise _lib.Yv1Error("this block's forward did not store y3 (two-pass conv3): its backward needs the masked "
-                                "gradient + column sums from the block above (bn3 as algebra)")
         if algebra:
             # bn3's reduce / finalize / apply passes and conv3's ordinary dgrad + wgrad, as four GEMM-side steps
             (grads[blk.bn3.weight], grads[blk.bn3.bias], grads[blk.conv3.weight]) = ops.bn3_algebra_backward(
@@ -368,13 +352,12 @@ class ResNet(HipBackbone):
         nblk = len(rec["blocks"])
         blocks = rec["blocks"]
         g_sum = None
-        alg = self._algebra_block_ids()
         for bi, brec in enumerate(reversed(blocks)):
             side.wide = nblk - bi <= self.wgrad_wide_tail
             fi = nblk - 1 - bi                                        # forward index of this block
             # the block below (processed next) runs its bn3 backward as algebra when it is an eligible identity block AND
             # this block's conv1 data gradient is the one that produces its output gradient (identity shortcut here)
-            below = blocks[fi - 1] if (fi > 0 and id(blocks[fi - 1][0]) in alg and blocks[fi - 1][13] is not None) else None
+            below = blocks[fi - 1] if (fi > 0 and self._bn3_algebra_ok(blocks[fi - 1])) else None
             res = self.block_backward(brec, g, grads, side if nblk - bi > self.wgrad_main_tail else inline,
                                       g_sum=g_sum, below=below)
             g, g_sum = res if isinstance(res, tuple) else (res, None)

@@ -70,9 +70,6 @@ struct ConvArgs {
   const unsigned char* OM = nullptr;   // optional OUTPUT mask [dest pixels][ldom bytes] (bit k of byte j = channel 8j+k): channels
   int ldom = 0;                        //   whose bit is 0 are stored as zero (the ReLU mask of the block whose output gradient this is)
   float* gsum = nullptr;               // optional [MT][Cout] per-tile column sums of the values this launch ADDED to the destination
-  int no_store = 0;                    // statistics-only launch: the output tile is not written (conv3 of an algebra block, pass 1)
-  unsigned char* RM = nullptr;         // optional OUTPUT: 1-bit sign mask of the stored values [M][ldrm bytes] (pass 2: the block's
-  int ldrm = 0;                        //   ReLU mask, what yv1_bn_apply writes)
   int M;
   int MT, NT;
   int slots = 0;       // k_conv_ps: workgroups per column tile; workgroup (slot, nt) walks the pixel tiles slot, slot+slots, ...
@@ -171,7 +168,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     o[a.Cout] = ss;
   }
 
-  if (a.no_store) return;                                // statistics-only launch (uniform: every thread of every workgroup)
   // ---- epilogue 3: full-line stores, 16 B (8 channels) per lane
   constexpr int OCPR = BN / 8;
   constexpr int OPASSES = (BM * OCPR + NTH - 1) / NTH;
@@ -291,16 +287,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
           res[k] = pack_bf16x2(lo, hi);
         }
         v = make_uint4(res[0], res[1], res[2], res[3]);
-      }
-      if (a.RM) {
-        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
-        unsigned mb = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          mb |= (__uint_as_float(pv[k] << 16) > 0.f ? 1u : 0u) << (2 * k);
-          mb |= (__uint_as_float(pv[k] & 0xffff0000u) > 0.f ? 1u : 0u) << (2 * k + 1);
-        }
-        a.RM[(size_t)m * a.ldrm + ((n0 + cc * 8) >> 3)] = (unsigned char)mb;
       }
       if (a.OM) {                                         // zero the channels the destination block's ReLU closed
         const unsigned mb = om_pre[i];
@@ -1282,7 +1268,6 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
       }
     }
     const bool affine = !PLAIN && (a.escale != nullptr || a.erelu);
-    if (!a.no_store)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1385,23 +1370,13 @@ __global__ void __launch_bounds__(WM * WN * 64, (ps_wgs_per_cu<BM, BN, BK, NST>(
               }
               v = make_uint4(res[0], res[1], res[2], res[3]);
             }
-            if (!PLAIN && a.RM) {
-              const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
-              unsigned mb = 0;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                mb |= (__uint_as_float(pv[k] << 16) > 0.f ? 1u : 0u) << (2 * k);
-                mb |= (__uint_as_float(pv[k] & 0xffff0000u) > 0.f ? 1u : 0u) << (2 * k + 1);
-              }
-              a.RM[(size_t)m * a.ldrm + (nch >> 3)] = (unsigned char)mb;
-            }
             *reinterpret_cast<uint4*>(a.Y + off) = v;
           }
         }
       }
     }
     // the counted waits of the next tile's first steps may skip ESTORES stores only if every wave certainly issued them
-    after_epilogue = (more && full && !a.no_store) ? 1 : 0;
+    after_epilogue = (more && full) ? 1 : 0;
   }
 #undef YV1_STEP_P
 #undef YV1_SET_TAP_P
@@ -1850,52 +1825,6 @@ extern "C" int yv1_conv2d_fwd_bn_act_nhwc_bf16(const void* x, const void* w, voi
   a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = k; a.Kw = k * k * Cin;
   a.M = N * a.P * a.Q;
   a.escale = scale; a.eshift = shift; a.ERES = (const bf16_t*)residual; a.ldres = ldres; a.erelu = relu;
-  return dispatch(a, stream);
-}
-
-// Forward convolution that writes ONLY the BatchNorm statistic partials (stats, as yv1_conv2d_fwd_nhwc_bf16): pass 1 of a
-// pointwise convolution whose raw output is never stored (conv3 of a Bottleneck whose BatchNorm-3 backward runs as algebra:
-// nothing reads y3 any more).  Pass 2 is yv1_conv2d_fwd_bn_act_mask_nhwc_bf16 with the finalized scale / shift.
-extern "C" int yv1_conv2d_fwd_stats_only_nhwc_bf16(const void* x, const void* w, int N, int IH, int IW, int ldx, int Cin,
-                                                   int Cout, int k, int stride, int pad, float* stats, hipStream_t stream) {
-  yv1_cfg_reset();
-  if (!x || !w || !stats || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
-  ConvArgs a;
-  a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
-  a.escale = a.eshift = nullptr; a.ERES = nullptr; a.ldres = 0; a.erelu = 0;
-  a.X = (const bf16_t*)x; a.W = (const bf16_t*)w; a.Y = nullptr; a.stats = stats;
-  a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx;
-  a.P = (IH + 2 * pad - k) / stride + 1; a.Q = (IW + 2 * pad - k) / stride + 1;
-  a.Cin = Cin; a.Cout = Cout; a.R = k; a.S = k;
-  a.ah = stride; a.bh = 1; a.ch = -pad; a.aw = stride; a.bw = 1; a.cw = -pad; a.log2d = 0;
-  a.OH = a.P; a.OW = a.Q; a.ldy = Cout; a.os = 1; a.accumulate = 0;
-  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = k; a.Kw = k * k * Cin;
-  a.M = N * a.P * a.Q;
-  a.no_store = 1;
-  return dispatch(a, stream);
-}
-
-// yv1_conv2d_fwd_bn_act_nhwc_bf16 that also writes the 1-bit sign mask of its output ([pixels][ldmask bytes], the layout
-// of yv1_bn_apply's relu_mask): out = relu(bf16(acc * scale + shift) + residual), mask = out > 0.
-extern "C" int yv1_conv2d_fwd_bn_act_mask_nhwc_bf16(const void* x, const void* w, void* y, int N, int IH, int IW, int ldx,
-                                                    int Cin, int Cout, int ldy, int k, int stride, int pad, const float* scale,
-                                                    const float* shift, const void* residual, int ldres, int relu,
-                                                    void* relu_mask, int ldmask, hipStream_t stream) {
-  yv1_cfg_reset();
-  if (!x || !w || !y || !scale || !shift || N <= 0 || k <= 0 || stride <= 0) return YV1_ERR_BAD_ARG;
-  if (residual && ldres % 8) return YV1_ERR_UNSUPPORTED;
-  ConvArgs a;
-  a.AS = nullptr; a.AM = nullptr; a.ldas = a.ldam = 0;
-  a.X = (const bf16_t*)x; a.W = (const bf16_t*)w; a.Y = (bf16_t*)y; a.stats = nullptr;
-  a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx;
-  a.P = (IH + 2 * pad - k) / stride + 1; a.Q = (IW + 2 * pad - k) / stride + 1;
-  a.Cin = Cin; a.Cout = Cout; a.R = k; a.S = k;
-  a.ah = stride; a.bh = 1; a.ch = -pad; a.aw = stride; a.bw = 1; a.cw = -pad; a.log2d = 0;
-  a.OH = a.P; a.OW = a.Q; a.ldy = ldy; a.os = 1; a.accumulate = 0;
-  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = k; a.Kw = k * k * Cin;
-  a.M = N * a.P * a.Q;
-  a.escale = scale; a.eshift = shift; a.ERES = (const bf16_t*)residual; a.ldres = ldres; a.erelu = relu;
-  a.RM = (unsigned char*)relu_mask; a.ldrm = ldmask;
   return dispatch(a, stream);
 }
 

@@ -149,32 +149,6 @@ def conv_fwd(x, w, y, want_stats=True):
     return stats
 
 
-def conv_fwd_stats_only(x, w, npix_out):
-    """BatchNorm-statistic partials of conv(x, w) WITHOUT storing the convolution output (pass 1 of a two-pass pointwise
-    convolution, see conv_fwd_bn_act_mask)."""
-    dev = x.t.device
-    rows = lib().yv1_conv2d_stats_rows(npix_out, w.Opad, w.Ipad, w.k, w.stride, w.pad)
-    stats = _f32(rows * 2 * w.Opad, dev).view(rows, 2, w.Opad)
-    check(lib().yv1_conv2d_fwd_stats_only_nhwc_bf16(x.p, ptr(w.fwd), x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, w.k, w.stride, w.pad,
-                                                    ptr(stats), stream_ptr(dev)), "yv1_conv2d_fwd_stats_only_nhwc_bf16")
-    return stats
-
-
-def conv_fwd_bn_act_mask(x, w, y, st, relu=True, residual=None, want_mask=True):
-    """y = relu?(bf16(conv(x, w) * scale + shift) + residual) with the BatchNorm of ``st`` (a finalized TRAINING-mode BNState)
-    in the epilogue, + the 1-bit ReLU mask of y: pass 2 of the two-pass pointwise convolution -- the raw convolution output
-    is never written or re-read."""
-    dev = x.t.device
-    mask = ReluMask(y.npix, y.C, dev) if want_mask else None
-    check(lib().yv1_conv2d_fwd_bn_act_mask_nhwc_bf16(x.p, ptr(w.fwd), y.p, x.N, x.H, x.W, x.ld, w.Ipad, w.Opad, y.ld, w.k, w.stride,
-                                                     w.pad, ptr(st.scale), ptr(st.shift),
-                                                     residual.p if residual is not None else None,
-                                                     residual.ld if residual is not None else 0, 1 if relu else 0,
-                                                     mask.p if mask is not None else None, mask.ld if mask is not None else 0,
-                                                     stream_ptr(dev)), "yv1_conv2d_fwd_bn_act_mask_nhwc_bf16")
-    return mask
-
-
 def conv_fwd_bn_act(x, w, y, st, relu=True, residual=None):
     """Inference: y = relu?(bf16(conv(x, w) * scale + shift) + residual), ``st`` an eval-mode BNState."""
     dev = x.t.device
@@ -400,9 +374,6 @@ BN3_ALGEBRA_MAX_P = int(_os2.environ.get("YV1_BN3_ALGEBRA", "128"))
 # (3.4e-3 against the dual passes) and measured LEVEL (3038-3051 vs 3036-3039 img/s): the dual passes already share their
 # reads of the gradient and the mask, and the algebra puts two T GEMMs in front of the data gradients.  Off by default.
 BN3_ALGEBRA_PROJ = _os2.environ.get("YV1_BN3_ALGEBRA_PROJ", "0") == "1"
-# forward of the algebra blocks: conv3 in two passes (statistics only, then BatchNorm + add + ReLU in the epilogue): y3 never
-# exists (0 = keep the stored-y3 forward)
-BN3_TWO_PASS_FWD = _os2.environ.get("YV1_BN3_TWO_PASS", "1") != "0"
 
 
 def _gsum_rows_le32(gsum, dev):
