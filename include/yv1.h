@@ -250,6 +250,24 @@ int yv1_bn3_build(const void* w3, int p, int C4, const float* k1, const float* k
                   void* wcat, float* bias, yv1_stream_t stream);
 int yv1_bn3_dw(const float* T, const float* G, const float* sz_partials, int rows, const void* w3, int p, int C4,
                const float* k1, const float* k2, const float* k3is, const float* mean, float* dW, yv1_stream_t stream);
+/* Deferred BatchNorm backward (round 3): relu(bn(x)) feeding a pointwise convolution -- DenseNet's
+ * norm1 -> relu1 -> conv1 over the concatenated features (OriginDenseNet.py:22-27,:32-36) and the transitions' norm -> relu ->
+ * conv (:50-52).  dx = a*d - a*mean(d) - a*xhat*mean(d*xhat) with d the ReLU-masked gradient at the BatchNorm output and
+ * a = gamma*invstd:  the first term is added by the data gradient's own epilogue (which also emits the two sums per pixel
+ * tile: part [rows][2][Cin] = sum d, sum d*(x - mean)), the other two are affine in x per channel -- their coefficients of
+ * every layer that normalises the same features are summed in KA / KB by yv1_bn_bwd_finalize_deferred (which also returns
+ * dgamma / dbeta) and subtracted once by yv1_bn_deferred_fix before the gradient of those channels is consumed.  Replaces
+ * yv1_conv2d_dgrad_nhwc_bf16 + yv1_bn_bwd_reduce + yv1_bn_bwd_finalize + yv1_bn_bwd_apply(accumulate) there; the masked
+ * gradient tensor is never stored.  1x1, stride 1, pad 0; Cout (the convolution's output channels) % 64 == 0. */
+int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin,
+                                           int Cout, int lddy, const void* x, int ldx, const float* scale, const float* shift,
+                                           const float* mean, int accumulate, float* part, yv1_stream_t stream);
+int yv1_conv2d_dgrad_bn_deferred_rows(int M, int Cin, int Cout);
+int yv1_bn_bwd_finalize_deferred(const float* part, int rows, int C, float count, const float* gamma, const float* mean,
+                                 const float* invstd, float* dgamma, float* dbeta, float* KA, float* KB, int accumulate,
+                                 yv1_stream_t stream);   /* rows <= 2048 (yv1_reduce_rows first) */
+int yv1_bn_deferred_fix(void* g, int ldg, const void* x, int ldx, const float* KA, const float* KB, long long npix, int C,
+                        yv1_stream_t stream);            /* g -= KA + KB * x over a C-channel window */
 /* BatchNorm(+ReLU) backward behind the stem's 3x3/2 max pool (OriginResNet.py:174-177, OriginDenseNet.py:120-128; autograd
  * of nn.MaxPool2d + nn.ReLU + nn.BatchNorm2d): dpool [N,OH,OW,C] is the gradient of the pool OUTPUT, pool_idx what
  * yv1_maxpool3x3s2_fwd stored; the pool's backward is gathered on the fly, so the 4x larger gradient of the pool input is

@@ -33,6 +33,44 @@ def test_header_matches_ctypes_table_and_library_exports():
         assert nargs == len(_lib.SIGNATURES[s][1]), s
 
 
+def _proto_args(arglist):
+    return [re.sub(r"\s+", " ", a).strip() for a in arglist.split(",") if a.strip() and a.strip() != "void"]
+
+
+def test_argument_types_agree_between_header_ctypes_table_and_definitions():
+    """Type by type, not only by count: include/yv1.h against yolo_v1_amd/_lib.py's ctypes table and against every
+    extern "C" definition in csrc/*.hip (the sources do not include the public header, so the compiler checks neither)."""
+    import glob
+    from yolo_v1_amd import _lib
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "yv1.h")).read(), flags=re.S)
+    protos = {n: _proto_args(a) for _, n, a in re.findall(r"^(int|size_t)\s+(yv1_\w+)\s*\((.*?)\)\s*;", txt, flags=re.S | re.M)}
+    assert sorted(protos) == sorted(_lib.SIGNATURES)
+    scalar = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong, "size_t": ctypes.c_size_t,
+              "unsigned": ctypes.c_uint, "double": ctypes.c_double}
+
+    def ctype(a):
+        if "*" in a or "yv1_stream_t" in a or "hipStream_t" in a:
+            return ctypes.c_void_p
+        return scalar[a.rsplit(" ", 1)[0].replace("const ", "").strip()]
+
+    def kind(a):                               # pointer-ness + scalar type, names ignored
+        if "*" in a or "yv1_stream_t" in a or "hipStream_t" in a:
+            return "ptr"
+        return a.rsplit(" ", 1)[0].replace("const ", "").strip()
+
+    for name, args in protos.items():
+        want = [ctype(a) for a in args]
+        got = [ctypes.c_void_p if t is ctypes.c_char_p else t for t in _lib.SIGNATURES[name][1]]
+        assert want == got, (name, [(i, args[i]) for i, (w, g) in enumerate(zip(want, got)) if w != g])
+    seen = set()
+    for f in glob.glob(os.path.join(ROOT, "yolo_v1_amd", "csrc", "*.hip")):
+        src = re.sub(r"//[^\n]*", "", open(f).read())
+        for _, name, a in re.findall(r'extern "C"\s+(int|size_t)\s+(yv1_\w+)\s*\((.*?)\)\s*\{', src, flags=re.S):
+            seen.add(name)
+            assert [kind(x) for x in _proto_args(a)] == [kind(x) for x in protos[name]], (os.path.basename(f), name)
+    assert seen == set(protos), set(protos) ^ seen
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     import pytest
     from yolo_v1_amd import _lib

@@ -116,14 +116,19 @@ class DenseNet(HipBackbone):
         ops.conv_fwd(t, wc, yc, False)
         return ("trans", tr, buf, st, t, yc)
 
-    def layer_backward(self, lrec, buf, G, grads, side):
+    def layer_backward(self, lrec, buf, G, grads, side, K=None, owed=False):
         """Backward of one _DenseLayer: ``G`` holds the gradient of the block buffer; the layer's own slice is complete
-        (every later layer has added to it), its input gradient is accumulated into G[..., :cin]."""
+        (every later layer has added to it), its input gradient is accumulated into G[..., :cin].
+        ``K`` ([2][Ctot] fp32, ops.BN_DEFERRED): norm1's backward is deferred -- conv1's data gradient adds scale * masked
+        gradient to G in its epilogue, the mean terms of every BatchNorm over a channel are summed in K and subtracted from
+        that channel's gradient here, right before it is consumed (``owed``: a later layer has put something into K)."""
         (layer, cin, st1, t1, y1, st2, t2) = lrec
         dev = G.t.device
         N = G.N
         w1, w2 = self.cw(layer.conv1), self.cw(layer.conv2)
         dy2 = G.window(cin, self.growth)
+        if K is not None and owed:
+            ops.bn_deferred_fix(dy2, buf.window(cin, self.growth), K[:, cin:cin + self.growth])
         mk = side.mark()
         dt2 = ops.new_act(N, t2.H, t2.W, t2.C, dev)
         ops.conv_dgrad(dy2, w2, dt2)
@@ -131,16 +136,23 @@ class DenseNet(HipBackbone):
         dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
         grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward(dt2, y1, st2, layer.norm2, dy1, 2)
         mk = side.mark()
-        dt1 = ops.new_act(N, t1.H, t1.W, cin, dev)
-        ops.conv_dgrad(dy1, w1, dt1)
-        grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1, side, after=mk)
-        grads[layer.norm1.weight], grads[layer.norm1.bias] = ops.bn_backward(
-            dt1, buf.window(0, cin), st1, layer.norm1, G.window(0, cin), 2, accumulate=True)
+        if K is not None:
+            part = ops.conv_dgrad_bn_deferred(dy1, w1, G.window(0, cin), buf.window(0, cin), st1, accumulate=True)
+            grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1, side, after=mk)
+            grads[layer.norm1.weight], grads[layer.norm1.bias] = ops.bn_bwd_finalize_deferred(
+                part, buf.npix, layer.norm1, st1, K[:, :cin], accumulate=True)
+        else:
+            dt1 = ops.new_act(N, t1.H, t1.W, cin, dev)
+            ops.conv_dgrad(dy1, w1, dt1)
+            grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1, side, after=mk)
+            grads[layer.norm1.weight], grads[layer.norm1.bias] = ops.bn_backward(
+                dt1, buf.window(0, cin), st1, layer.norm1, G.window(0, cin), 2, accumulate=True)
         self._emit(grads, list(layer.parameters()))
 
-    def transition_backward(self, trec, g_first, grads, side):
+    def transition_backward(self, trec, g_first, grads, side, K=None):
         """Backward of one _Transition: ``g_first`` is the gradient of the pooled tensor; returns the gradient of the
-        preceding block buffer."""
+        preceding block buffer.  ``K``: the preceding block's deferred-correction table (see layer_backward) -- the
+        transition's BatchNorm is the first to write into it."""
         _, tr, buf, st, t, yc = trec
         dev = g_first.t.device
         N = buf.N
@@ -148,11 +160,17 @@ class DenseNet(HipBackbone):
         dyc = ops.new_act(N, yc.H, yc.W, yc.C, dev)
         ops.avgpool_bwd(g_first, dyc)
         mk = side.mark()
-        dt = ops.new_act(N, t.H, t.W, t.C, dev)
-        ops.conv_dgrad(dyc, wc, dt)
-        grads[tr.conv.weight] = ops.conv_wgrad(t, dyc, wc, side, after=mk)
         G = ops.new_act(N, buf.H, buf.W, buf.C, dev)
-        grads[tr.norm.weight], grads[tr.norm.bias] = ops.bn_backward(dt, buf, st, tr.norm, G, 2)
+        if K is not None:
+            part = ops.conv_dgrad_bn_deferred(dyc, wc, G, buf, st, accumulate=False)
+            grads[tr.conv.weight] = ops.conv_wgrad(t, dyc, wc, side, after=mk)
+            grads[tr.norm.weight], grads[tr.norm.bias] = ops.bn_bwd_finalize_deferred(part, buf.npix, tr.norm, st, K,
+                                                                                      accumulate=False)
+        else:
+            dt = ops.new_act(N, t.H, t.W, t.C, dev)
+            ops.conv_dgrad(dyc, wc, dt)
+            grads[tr.conv.weight] = ops.conv_wgrad(t, dyc, wc, side, after=mk)
+            grads[tr.norm.weight], grads[tr.norm.bias] = ops.bn_backward(dt, buf, st, tr.norm, G, 2)
         self._emit(grads, list(tr.parameters()))
         return G
 
@@ -261,14 +279,29 @@ class DenseNet(HipBackbone):
         grads[F.norm5.weight], grads[F.norm5.bias] = ops.bn_backward(dt5, buf, st5, F.norm5, G, 2)
         self._emit(grads, [self.bn_end.weight, self.bn_end.bias, self.layer6.weight, F.norm5.weight, F.norm5.bias])
 
+        # deferred BatchNorm backward (ops.BN_DEFERRED): K = per-block [2][Ctot] table of the affine corrections the norm1s /
+        # the transition norm owe the gradient of each feature channel.  The LAST block's buffer gradient comes from norm5's
+        # ordinary backward (its convolution has 32 padded output channels: K of the GEMM too short for the ring kernels),
+        # so its table starts at zero.
+        deferred = ops.BN_DEFERRED
+        K, owed = None, False
         for stage in reversed(rec["stages"]):
             if stage[0] == "block":
                 _, buf, lrecs, nf = stage
+                if deferred and K is None:
+                    K = torch.zeros((2, buf.C), dtype=torch.float32, device=dev)
                 for lrec in reversed(lrecs):
-                    self.layer_backward(lrec, buf, G, grads, side)
+                    self.layer_backward(lrec, buf, G, grads, side, K, owed)
+                    owed = owed or K is not None
                 g_first = G.window(0, nf)                     # gradient w.r.t. the pooled tensor that opened the block
+                if K is not None and owed:
+                    ops.bn_deferred_fix(g_first, buf.window(0, nf), K[:, :nf])
+                K, owed = None, False
             else:
-                G = self.transition_backward(stage, g_first, grads, side)
+                if deferred:
+                    K = torch.empty((2, stage[2].C), dtype=torch.float32, device=dev)
+                    owed = True
+                G = self.transition_backward(stage, g_first, grads, side, K)
 
         xp, y0, s0, z0, H, W, pidx = rec["stem"]
         w0 = self.cw(F.conv0, stem=True)

@@ -304,9 +304,10 @@ class ResNet(HipBackbone):
         elif yd is not None and below is not None:
             # the block below runs its bn3 backward as algebra: both data gradients store its output gradient masked by ITS
             # ReLU mask and report the column sums of what they added
-            s_a = ops.conv_dgrad_out(dy1, w1, g_in, False, below[13])
-            s_b = ops.conv_dgrad_out(dyd, wd, g_in, True, below[13])
-            sums = torch.cat([s_a, s_b], 0)
+            ra, rb = ops.dgrad_gsum_rows(dy1, w1), ops.dgrad_gsum_rows(dyd, wd)
+            sums = torch.empty((ra + rb, g_in.C), dtype=torch.float32, device=dev)
+            ops.conv_dgrad_out(dy1, w1, g_in, False, below[13], gsum=sums[:ra])
+            ops.conv_dgrad_out(dyd, wd, g_in, True, below[13], gsum=sums[ra:])
         elif yd is not None:
             ops.conv_dgrad(dy1, w1, g_in, accumulate=False)
             ops.conv_dgrad(dyd, wd, g_in, accumulate=True)      # strided 1x1: scatter-accumulate

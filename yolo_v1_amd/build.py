@@ -27,6 +27,7 @@ SOURCES = {
     "optim.hip": [],
     "cfglog.hip": [],
     "bn3alg.hip": [],
+    "bn_deferred.hip": [],
 }
 
 

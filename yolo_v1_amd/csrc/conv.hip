@@ -70,6 +70,15 @@ struct ConvArgs {
   const unsigned char* OM = nullptr;   // optional OUTPUT mask [dest pixels][ldom bytes] (bit k of byte j = channel 8j+k): channels
   int ldom = 0;                        //   whose bit is 0 are stored as zero (the ReLU mask of the block whose output gradient this is)
   float* gsum = nullptr;               // optional [MT][Cout] per-tile column sums of the values this launch ADDED to the destination
+  // round 3, "deferred BatchNorm backward" (DenseNet norm1 / transition norm): the launch's output is the
+  // gradient at the OUTPUT of relu(bn(x)); the epilogue masks it (scale*x + shift > 0), adds scale * masked to the destination
+  // (the reduction-free term of the BatchNorm backward) and emits the per-tile sums the finalize needs
+  const bf16_t* DBX = nullptr;         // the BatchNorm's INPUT x [M][lddbx] (k_conv_dma<..., DB = true> only)
+  int lddbx = 0;
+  const float* dbscale = nullptr;      // forward scale / shift / mean of that BatchNorm per GEMM column
+  const float* dbshift = nullptr;
+  const float* dbmean = nullptr;
+  float* dbpart = nullptr;             // [MT][2][Cout]: sum(d), sum(d * (x - mean)) with d = masked gradient (bf16 values)
   int M;
   int MT, NT;
   int slots = 0;       // k_conv_ps: workgroups per column tile; workgroup (slot, nt) walks the pixel tiles slot, slot+slots, ...
@@ -93,7 +102,7 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // Shared epilogue of the GEMM kernels: BatchNorm statistic partials from the fp32 accumulators, DPP lane swap +
 // packed rounding into a bf16 LDS tile, full-line stores (optionally accumulating / adding the masked shortcut
 // gradient).  The caller has finished its last LDS read (barrier) before the tile overwrites the staging buffers.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DB = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const ConvArgs& a,
                                               unsigned char* smem, int m0, int n0, int mt) {
   constexpr int NTH = WM * WN * 64;
@@ -171,6 +180,66 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
   // ---- epilogue 3: full-line stores, 16 B (8 channels) per lane
   constexpr int OCPR = BN / 8;
   constexpr int OPASSES = (BM * OCPR + NTH - 1) / NTH;
+  if constexpr (DB) {
+    // deferred BatchNorm backward (see ConvArgs::DBX): destination pixels are the GEMM pixels (os == 1)
+    static_assert(NTH % OCPR == 0, "a thread keeps its channel chunk across the store passes");
+    constexpr int RG = NTH / OCPR;
+    const int cc = tid % OCPR, rg = tid / OCPR;
+    float sc[8], sh[8], mu[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sc[k] = a.dbscale[n0 + cc * 8 + k]; sh[k] = a.dbshift[n0 + cc * 8 + k]; mu[k] = a.dbmean[n0 + cc * 8 + k];
+      s1[k] = 0.f; s2[k] = 0.f;
+    }
+    uint4 x_pre[OPASSES], old_pre[OPASSES];
+#pragma unroll
+    for (int i = 0; i < OPASSES; ++i) {
+      const int row = rg + i * RG, m = m0 + row;
+      x_pre[i] = make_uint4(0u, 0u, 0u, 0u); old_pre[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (row < BM && m < a.M) {
+        x_pre[i] = *reinterpret_cast<const uint4*>(a.DBX + (size_t)m * a.lddbx + n0 + cc * 8);
+        if (a.accumulate) old_pre[i] = *reinterpret_cast<const uint4*>(a.Y + (size_t)m * a.ldy + n0 + cc * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < OPASSES; ++i) {
+      const int row = rg + i * RG, m = m0 + row;
+      if (row < BM && m < a.M) {
+        const uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
+        const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
+        const unsigned* px = reinterpret_cast<const unsigned*>(&x_pre[i]);
+        const unsigned* po = reinterpret_cast<const unsigned*>(&old_pre[i]);
+        unsigned res[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xl = __uint_as_float(px[k] << 16), xh = __uint_as_float(px[k] & 0xffff0000u);
+          const float dl = (xl * sc[2 * k] + sh[2 * k]) > 0.f ? __uint_as_float(pv[k] << 16) : 0.f;
+          const float dh = (xh * sc[2 * k + 1] + sh[2 * k + 1]) > 0.f ? __uint_as_float(pv[k] & 0xffff0000u) : 0.f;
+          s1[2 * k] += dl; s1[2 * k + 1] += dh;
+          s2[2 * k] += dl * (xl - mu[2 * k]); s2[2 * k + 1] += dh * (xh - mu[2 * k + 1]);
+          res[k] = pack_bf16x2(__uint_as_float(po[k] << 16) + sc[2 * k] * dl,
+                               __uint_as_float(po[k] & 0xffff0000u) + sc[2 * k + 1] * dh);
+        }
+        *reinterpret_cast<uint4*>(a.Y + (size_t)m * a.ldy + n0 + cc * 8) = make_uint4(res[0], res[1], res[2], res[3]);
+      }
+    }
+    // fixed-order reduction over the RG threads that hold the same channel chunk; the epilogue tile is dead
+    __syncthreads();
+    float* r1 = reinterpret_cast<float*>(smem);            // [RG][BN]
+    float* r2 = r1 + RG * BN;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { r1[rg * BN + cc * 8 + k] = s1[k]; r2[rg * BN + cc * 8 + k] = s2[k]; }
+    __syncthreads();
+    if (tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < RG; ++r) { t1 += r1[r * BN + tid]; t2 += r2[r * BN + tid]; }
+      float* o = a.dbpart + (size_t)mt * 2 * a.Cout + n0 + tid;
+      o[0] = t1;
+      o[a.Cout] = t2;
+    }
+    return;
+  }
   // shortcut-gradient operands of ALL passes up front: inside the loop every load sits behind the previous pass's store
   // (the compiler cannot prove Y and AS apart), i.e. one memory round trip per pass instead of one per tile
   uint4 as_pre[OPASSES];
@@ -505,7 +574,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NST>
+template <int BM, int BN, int BK, int WM, int WN, int NST, bool DB = false>
 __global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128 * 128 ? 3 : 2))) k_conv_dma(ConvArgs a) {
   constexpr int NTH = WM * WN * 64;
   constexpr int CPR = BK / 8;
@@ -694,7 +763,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128
 #undef YV1_SET_TAP_D
 #undef YV1_ISSUE
   __syncthreads();                                     // all fragment reads done before the epilogue tile reuses LDS
-  conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
+  conv_epilogue<BM, BN, WM, WN, DB>(acc, a, smem, m0, n0, mt);
 }
 
 // ---- 3x3 stride-1 convolutions: the three taps of a filter row share ONE A tile (round 3) -------------------------
@@ -1503,20 +1572,21 @@ int launch_ps(ConvArgs& a, hipStream_t stream) {
   return YV1_OK;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NST>
+template <int BM, int BN, int BK, int WM, int WN, int NST, bool DB = false>
 int launch_dma(ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
   constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
   constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
+  static_assert(!DB || LDS >= (size_t)2 * 8 * WM * WN * 64 * 4, "the deferred-BatchNorm sums reduce through 2 x [RG][BN] floats");
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
-  auto kern = k_conv_dma<BM, BN, BK, WM, WN, NST>;
+  auto kern = k_conv_dma<BM, BN, BK, WM, WN, NST, DB>;
   if (LDS > 64 * 1024) YV1_SET_MAX_LDS(kern, LDS);
   {
     const bool direct = a.R * a.S == 1 && a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0 && a.log2d == 0 &&
                         a.P == a.IH && a.Q == a.IW;         // the kernel's own condition for its direct addressing
-    yv1_cfg_note("k_conv_dma<%d,%d,%d,%d,%d,%d>%s", BM, BN, BK, WM, WN, NST, direct ? " direct" : "");
+    yv1_cfg_note("k_conv_dma<%d,%d,%d,%d,%d,%d>%s%s", BM, BN, BK, WM, WN, NST, direct ? " direct" : "", DB ? " bn-deferred" : "");
   }
   hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), LDS, stream, a);
   YV1_LAUNCH_CHECK();
@@ -1693,6 +1763,16 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps, bool s1p1 = false) {
   return p;
 }
 
+// tile of a deferred-BatchNorm data gradient (1x1, K = Cin a multiple of 64): choose_cfg's tile, the ring depth fixed per tile
+ConvPlan plan_deferred(int M, int Cout, int Cin) {
+  ConvPlan p;
+  p.kind = 1;
+  p.bm = choose_cfg(M, Cout, Cin, &p.bn);
+  p.bk = (p.bn == 32 || p.bm == 64) ? 64 : 32;
+  p.nst = 3;
+  return p;
+}
+
 // every (tile, K-step, stage count) the ring kernels are instantiated for
 #define YV1_RING_CASES                 \
   YV1_RING_CASE(128, 256, 32, 2, 2, 3) \
@@ -1736,6 +1816,17 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
   static int as_min_m = -1;
   if (as_min_m < 0) as_min_m = env_int("YV1_AS_DMA_MIN_M", 0);
   if (p.kind == 2 && a.AS && a.M >= as_min_m) p.kind = 1;
+  if (a.DBX) {
+    // deferred BatchNorm backward: a 1x1 stride-1 data gradient through k_conv_dma<..., DB = true>, one tile per workgroup
+    // (yv1_conv2d_dgrad_bn_deferred_rows() = its pixel tiles)
+    if (a.R * a.S != 1 || a.os != 1 || a.AS || a.OM || a.gsum || a.X2 || a.stats || a.escale || a.ERES) return YV1_ERR_UNSUPPORTED;
+    p = plan_deferred(a.M, a.Cout, a.Cin);
+    if (p.bm == 128 && p.bn == 128) return launch_dma<128, 128, 32, 2, 2, 3, true>(a, stream);
+    if (p.bm == 128 && p.bn == 64) return launch_dma<128, 64, 32, 2, 2, 3, true>(a, stream);
+    if (p.bm == 64 && p.bn == 64) return launch_dma<64, 64, 64, 2, 2, 3, true>(a, stream);
+    if (p.bm == 128 && p.bn == 32) return launch_dma<128, 32, 64, 4, 1, 3, true>(a, stream);
+    return YV1_ERR_UNSUPPORTED;
+  }
   if (p.kind == 2 && (a.X2 || a.OM || a.gsum)) p.kind = 1;       // second K source / output mask / column sums: k_conv_dma only
   if (p.kind == 0 && (a.X2 || a.OM || a.gsum)) return YV1_ERR_UNSUPPORTED;
   if (p.kind == 0) {
@@ -1991,6 +2082,43 @@ extern "C" int yv1_conv2d_dgrad_out_nhwc_bf16(const void* dy, const void* wt, vo
   a.M = N * a.P * a.Q;
   a.OM = (const unsigned char*)out_mask; a.ldom = ldom; a.gsum = gsum;
   return dispatch(a, stream);
+}
+
+// Deferred BatchNorm backward (OriginDenseNet.py:22-27 norm1 -> relu1 -> conv1, :50-52 the transition's norm -> relu -> conv;
+// DESIGN.md section 7).  The 1x1 stride-1 pad-0 data gradient of a convolution whose input is relu(bn(x)), with the
+// reduction-FREE part of that BatchNorm's backward in the epilogue:
+//     d = bf16(dgrad(dy, wt)) where scale*x + shift > 0, else 0          (the gradient at the BatchNorm output)
+//     dx = (accumulate ? dx : 0) + scale * d                              (bf16, one rounding)
+//     part[tile][0][c] = sum_pixels d,  part[tile][1][c] = sum_pixels d * (x - mean[c])
+// What the BatchNorm backward subtracts from it -- scale * (mean(d) + xhat * mean(d * xhat)), an affine function of x per
+// channel -- is accumulated as coefficients by yv1_bn_bwd_finalize_deferred and applied once by yv1_bn_deferred_fix before the
+// gradient of those channels is consumed.  The stand-alone reduce and apply passes and the stored d tensor disappear.
+// x: the BatchNorm input [N,IH,IW,*] (pixel stride ldx), scale/shift/mean: its forward coefficients [Cin]; Cout (the
+// convolution's output channels = GEMM K) must be a multiple of 64.  part: [yv1_conv2d_dgrad_bn_deferred_rows()][2][Cin].
+extern "C" int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx,
+                                                      int Cin, int Cout, int lddy, const void* x, int ldx, const float* scale,
+                                                      const float* shift, const float* mean, int accumulate, float* part,
+                                                      hipStream_t stream) {
+  yv1_cfg_reset();
+  if (!dy || !wt || !dx || !x || !scale || !shift || !mean || !part || N <= 0) return YV1_ERR_BAD_ARG;
+  if (Cout % 64 || Cin % 32 || ldx % 8 || lddx % 8) return YV1_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx;
+  a.N = N; a.IH = IH; a.IW = IW; a.ldx = lddy;
+  a.Cin = Cout; a.Cout = Cin; a.R = 1; a.S = 1;
+  a.OH = IH; a.OW = IW; a.ldy = lddx; a.accumulate = accumulate ? 1 : 0;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = 1; a.Kw = Cout;
+  a.P = IH; a.Q = IW; a.os = 1;
+  a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
+  a.M = N * IH * IW;
+  a.DBX = (const bf16_t*)x; a.lddbx = ldx; a.dbscale = scale; a.dbshift = shift; a.dbmean = mean; a.dbpart = part;
+  return dispatch(a, stream);
+}
+
+// partial rows of yv1_conv2d_dgrad_bn_deferred_nhwc_bf16's sums: one per pixel tile of the kernel it dispatches
+extern "C" int yv1_conv2d_dgrad_bn_deferred_rows(int M, int Cin, int Cout) {
+  const ConvPlan p = plan_deferred(M, Cin, Cout);
+  return (M + p.bm - 1) / p.bm;
 }
 
 // partial rows of gsum for a 1x1 data gradient with M pixels, Cin (= GEMM columns) and Cout (= GEMM K): one per pixel tile

@@ -320,16 +320,25 @@ def conv_dgrad_add_masked_out(dy, w, dx, g, mask, out_mask=None, want_sum=False)
     return gsum
 
 
-def conv_dgrad_out(dy, w, dx, accumulate, out_mask, want_sum=True):
+def dgrad_gsum_rows(dy, w):
+    """Rows of column-sum partials the 1x1 data gradient of ``dy`` through ``w`` reports (one per pixel tile)."""
+    return lib().yv1_conv2d_dgrad_gsum_rows(dy.npix, w.Ipad, w.Opad)
+
+
+def conv_dgrad_out(dy, w, dx, accumulate, out_mask, want_sum=True, gsum=None):
     """conv_dgrad for a 1x1 pad-0 convolution (stride 1 | 2) whose result is the output gradient of the block below: stored
     masked by that block's ReluMask, with the per-tile column sums of what this launch added (see
-    conv_dgrad_add_masked_out).  Returns the partial rows or None."""
+    conv_dgrad_add_masked_out).  Returns the partial rows or None.  ``gsum``: a [dgrad_gsum_rows(dy, w)][dx.C] slice of a
+    caller-owned table to write the partials into (two launches into one block input: one table, no concatenation)."""
     if w.k != 1 or w.pad != 0:
         raise ValueError("conv_dgrad_out: 1x1 pad-0 convolution only")
     dev = dy.t.device
     L = lib()
-    gsum = None
-    if want_sum:
+    if gsum is not None:
+        rows = L.yv1_conv2d_dgrad_gsum_rows(dy.npix, w.Ipad, w.Opad)
+        if tuple(gsum.shape) != (rows, dx.C) or not gsum.is_contiguous() or gsum.dtype != torch.float32:
+            raise ValueError("conv_dgrad_out: gsum must be a contiguous fp32 [%d][%d] table" % (rows, dx.C))
+    elif want_sum:
         rows = L.yv1_conv2d_dgrad_gsum_rows(dy.npix, w.Ipad, w.Opad)
         gsum = _f32(rows * dx.C, dev).view(rows, dx.C)
     check(L.yv1_conv2d_dgrad_out_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld, w.stride,
@@ -339,14 +348,21 @@ def conv_dgrad_out(dy, w, dx, accumulate, out_mask, want_sum=True):
     return gsum
 
 
-def wgrad_raw(x, dy, shared=False):
+def wgrad_raw_buffers(x, dy):
+    """(out, workspace, workspace bytes) of wgrad_raw(x, dy): allocated by the caller when the launch itself happens on
+    another stream (SideStream: buffers belong to the main stream)."""
+    dev = x.t.device
+    out = torch.empty((dy.C, 1, x.C), dtype=torch.float32, device=dev)
+    wsb = lib().yv1_conv2d_wgrad_workspace_bytes(x.N, dy.H, dy.W, x.C, dy.C, 1)
+    return out, torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev), wsb
+
+
+def wgrad_raw(x, dy, shared=False, buffers=None):
     """fp32 [Cdy][1][Cx] = dy^T x over all pixels (the 1x1 weight-gradient GEMM on arbitrary operands: T = gm^T z2 and
     G = z2^T z2 of the bn3 algebra).  ``shared``: the split-K width for launches that run beside another stream."""
     dev = x.t.device
     L = lib()
-    out = torch.empty((dy.C, 1, x.C), dtype=torch.float32, device=dev)
-    wsb = L.yv1_conv2d_wgrad_workspace_bytes(x.N, dy.H, dy.W, x.C, dy.C, 1)
-    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    out, ws, wsb = buffers if buffers is not None else wgrad_raw_buffers(x, dy)
     fn = L.yv1_conv2d_wgrad_shared_nhwc_bf16 if shared else L.yv1_conv2d_wgrad_nhwc_bf16
     check(fn(x.p, dy.p, ptr(out), x.N, x.H, x.W, x.ld, x.C, dy.C, dy.ld, 1, 1, 0, ptr(ws), wsb, stream_ptr(dev)),
           "yv1_conv2d_wgrad_nhwc_bf16")
@@ -429,15 +445,18 @@ def bn3_algebra_backward(gm, gsum, z2, w3, st3, bn3, conv3_param, dz2, side, str
           "yv1_conv2d_dgrad_cat_bias_nhwc_bf16")
     dW = _grad_buf(conv3_param, (C4, 1, p))
 
+    # buffers of the side-stream launches are allocated HERE, on the main stream (SideStream: kept alive until join())
+    gbuf = wgrad_raw_buffers(z2, z2)
+    srows = L.yv1_bn_reduce_rows(z2.npix, p)
+    szp = _f32(srows * 2 * p, dev).view(srows, 2, p)
+
     def weight_side():
         overl = side.side is not None and not getattr(side, "wide", False)
-        G, ws_g = wgrad_raw(z2, z2, shared=overl)
-        szp = bn_stats(z2)
-        check(L.yv1_bn3_dw(ptr(T), ptr(G), ptr(szp), szp.shape[0], ptr(w3.fwd), p, C4, ptr(kk[0]), ptr(kk[1]), ptr(kk[2]),
+        G, _ = wgrad_raw(z2, z2, shared=overl, buffers=gbuf)
+        check(L.yv1_bn_stats(z2.p, z2.ld, z2.npix, p, ptr(szp), stream_ptr(dev)), "yv1_bn_stats")
+        check(L.yv1_bn3_dw(ptr(T), ptr(G), ptr(szp), srows, ptr(w3.fwd), p, C4, ptr(kk[0]), ptr(kk[1]), ptr(kk[2]),
                            ptr(st3.mean), ptr(dW), stream_ptr(dev)), "yv1_bn3_dw")
-        return G, ws_g, szp
-    keep = side.run(weight_side, z2.t, T, ws_t, kk, wcat, bias, dW, after=mk)
-    side.keep.append(keep)
+    side.run(weight_side, z2.t, T, ws_t, kk, wcat, bias, dW, gbuf[0], gbuf[1], szp, after=mk)
     if out_mask is not None:
         return dgam, dbet, dW.view(C4, 1, 1, p).permute(0, 3, 1, 2), osum
     return dgam, dbet, dW.view(C4, 1, 1, p).permute(0, 3, 1, 2)
@@ -876,6 +895,55 @@ def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=Fals
                              1 if accumulate else 0, s),
           "yv1_bn_bwd_apply")
     return dgam, dbet
+
+
+# "deferred BatchNorm backward" (csrc/bn_deferred.hip): DenseNet's norm1 / transition norm in front of
+# a pointwise convolution -- the reduction-free term rides in the data gradient's epilogue, the rest is summed as per-channel
+# coefficients and subtracted once per channel (0 = the dgrad + reduce + finalize + apply sequence)
+BN_DEFERRED = _os.environ.get("YV1_BN_DEFERRED", "1") != "0"
+
+
+def conv_dgrad_bn_deferred(dy, w, dx, x, st, accumulate=True):
+    """dx (+)= scale * mask * conv_transpose(dy, w) for the 1x1 stride-1 convolution ``w`` whose input was relu(bn(x)) with the
+    TRAINING-mode BNState ``st`` (mask = scale*x + shift > 0); returns the partial sums [rows][2][C] of the masked gradient
+    that bn_bwd_finalize_deferred turns into dgamma / dbeta and the correction coefficients."""
+    if w.k != 1 or w.stride != 1 or w.pad != 0:
+        raise ValueError("conv_dgrad_bn_deferred: 1x1 stride-1 pad-0 convolution only")
+    if (x.N, x.H, x.W, x.C) != (dx.N, dx.H, dx.W, dx.C) or x.C != w.Ipad:
+        raise ValueError("conv_dgrad_bn_deferred: x and dx must be the convolution input's window")
+    dev = dy.t.device
+    L = lib()
+    rows = L.yv1_conv2d_dgrad_bn_deferred_rows(dx.npix, w.Ipad, w.Opad)
+    part = _f32(rows * 2 * dx.C, dev)
+    check(L.yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld, x.p,
+                                                   x.ld, ptr(st.scale), ptr(st.shift), ptr(st.mean), 1 if accumulate else 0,
+                                                   ptr(part), stream_ptr(dev)), "yv1_conv2d_dgrad_bn_deferred_nhwc_bf16")
+    return part.view(rows, 2, dx.C)
+
+
+def bn_bwd_finalize_deferred(part, count, bn, st, K, accumulate=True):
+    """Partial sums of conv_dgrad_bn_deferred -> (dgamma, dbeta) of module ``bn``; the affine correction this BatchNorm owes
+    the gradient of its input channels is added to (``accumulate``) or stored in K = [2][C] (rows KA, KB)."""
+    dev = part.device
+    rows, _, C = part.shape
+    flat, rows = _shrink_partials(part.reshape(-1), rows, 2 * C, dev)
+    if _ARENA[0] is not None:
+        dgam, dbet = _grad_buf(bn.weight, (C,)), _grad_buf(bn.bias, (C,))
+    else:
+        gb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        dgam, dbet = gb[0], gb[1]
+    check(lib().yv1_bn_bwd_finalize_deferred(ptr(flat), rows, C, float(count), ptr(bn.weight), ptr(st.mean), ptr(st.invstd),
+                                             ptr(dgam), ptr(dbet), ptr(K[0]), ptr(K[1]), 1 if accumulate else 0,
+                                             stream_ptr(dev)), "yv1_bn_bwd_finalize_deferred")
+    return dgam, dbet
+
+
+def bn_deferred_fix(g, x, K):
+    """g -= KA + KB * x over the channel window ``g`` / ``x`` share (K = [2][C] rows for exactly that window)."""
+    if (g.N, g.H, g.W, g.C) != (x.N, x.H, x.W, x.C) or K.shape[1] != g.C:
+        raise ValueError("bn_deferred_fix: g, x and K must cover the same channel window")
+    check(lib().yv1_bn_deferred_fix(g.p, g.ld, x.p, x.ld, ptr(K[0]), ptr(K[1]), g.npix, g.C, stream_ptr(g.t.device)),
+          "yv1_bn_deferred_fix")
 
 
 def bn_backward_dual(dz, mask, a, b):

@@ -104,6 +104,7 @@ class GraphedStep:
     execs that are still alive in this process (DESIGN.md section 4 has the fault this was found through).
     """
     _LIVE = weakref.WeakSet()
+    _PARKED = []
 
     @classmethod
     def live_graphs(cls):
@@ -124,8 +125,11 @@ class GraphedStep:
         graphs = self._all_graphs()
         if graphs and torch.cuda.is_available():
             torch.cuda.synchronize()
-        for g in graphs:
-            g.reset()
+        if os.environ.get("YV1_GRAPH_DEFER_DESTROY"):          # diagnosis only: park the execs instead of destroying them
+            GraphedStep._PARKED.extend(graphs)
+        else:
+            for g in graphs:
+                g.reset()
         self.graphs, self.graph, self.graph2 = [], None, None
         self.loss = None
         self.phases, self.phase1 = [], None
