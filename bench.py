@@ -215,7 +215,7 @@ def other_training_config(backbone, S, batch, device, fp8_forward=False, steps=8
         out["hbm_frac"] = round(traffic / (ms * 1e-3) / 8e12, 4) if traffic else None
         if not traffic:
             out["traffic_note"] = prov.get("note")
-    graphed.close()            # the hipGraphExec, its private pool (all saved activations) and its streams go back NOW
+    graphed.close()            # retire the exec (train.GraphedStep.close: destruction is deferred, its pool stays until then)
     del graphed, net, opt, loss_layer
     torch.cuda.empty_cache()
     return out
@@ -418,7 +418,7 @@ def main():
         headline = args.backbone == "resnet" and args.S == 7 and not args.fp8_forward
         if world == 1 and args.other_configs and headline and graphed is not None:
             # BASELINE.json configs 3 and 5 in the same run (driver-visible), after the headline timed region
-            graphed.close()                # destroy the headline step's hipGraphExec before the next captures (train.GraphedStep)
+            graphed.close()                # retire the headline step's hipGraphExec before the next captures (train.GraphedStep)
             graphed = None
             torch.cuda.empty_cache()
             oc = {}

@@ -11,6 +11,7 @@ One process per GPU; with WORLD_SIZE > 1 the gradients are averaged over RCCL by
 Evaluation (train.py:187-198) lives in ``yolo_v1_amd.eval``.
 """
 import argparse
+import collections
 import os
 import time
 import weakref
@@ -99,12 +100,27 @@ class GraphedStep:
     memory pool (all saved activations: ~23 GB for ResNet-50 at batch 64).  None of that is returned before the exec is
     destroyed, and Python only destroys it when the last reference goes -- which for an object reachable from a frame,
     a closure or an autograd graph means "at some later garbage collection".  ``close()`` (or ``with GraphedStep(...) as
-    step:``) releases everything deterministically; a process that builds one captured step after another (bench.py's
-    ``other_configs``, a train-then-evaluate script, the test suite) must call it.  ``GraphedStep.live_graphs()`` counts the
+    step:``) retires them deterministically (destruction itself is deferred by ``PARK`` retirements, see close()); a process
+    that builds one captured step after another (bench.py's ``other_configs``, a train-then-evaluate script, the test suite)
+    must call it.  ``GraphedStep.live_graphs()`` counts the
     execs that are still alive in this process (DESIGN.md section 4 has the fault this was found through).
     """
     _LIVE = weakref.WeakSet()
-    _PARKED = []
+    # closed steps' execs, oldest first: destroyed only once PARK newer ones have been closed after them (see close())
+    _PARKED = collections.deque()
+    PARK = int(os.environ.get("YV1_GRAPH_PARK", "8"))
+
+    @classmethod
+    def parked_graphs(cls):
+        return len(cls._PARKED)
+
+    @classmethod
+    def drain(cls, keep=0):
+        """Destroys parked execs (oldest first) until ``keep`` are left; the device is synchronised first."""
+        if len(cls._PARKED) > keep and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        while len(cls._PARKED) > keep:
+            cls._PARKED.popleft().reset()
 
     @classmethod
     def live_graphs(cls):
@@ -119,17 +135,23 @@ class GraphedStep:
         return gs
 
     def close(self):
-        """Destroys the hipGraphExec objects (``CUDAGraph.reset()``: the runtime's per-exec streams, argument pools and
-        the private memory pool go back now, not at the next garbage collection) and drops every reference this object
-        holds -- the static buffers, the network, the gradient arena.  Idempotent; the object is unusable afterwards."""
+        """Retires the hipGraphExec objects and drops every reference this object holds -- the static buffers, the network,
+        the gradient arena.  Idempotent; the object is unusable afterwards.
+
+        The execs are not destroyed on the spot: they go to the back of a queue and ``CUDAGraph.reset()`` (the runtime's
+        per-exec streams, argument pools and the graph's private memory pool) runs on the OLDEST one once ``PARK`` (8,
+        ``YV1_GRAPH_PARK``) newer execs have been retired after it -- deterministic, but late.  Reason (DESIGN.md section
+        4): with the HIP runtime torch 2.10+rocm7.0 ships, destroying an exec that has a side branch and then building /
+        launching the next one corrupts the host heap now and then (round 2: SIGSEGV in hipGraphLaunch; round 3: glibc
+        abort / SIGSEGV in unrelated tensor destructors, 4 of 7 suite runs); it never did with destruction deferred
+        (tools/graph_accumulate_probe.py --defer 8: 512 cycles; the suite with parked execs), without the side stream, or
+        in a process that destroys nothing.  ``GraphedStep.drain()`` empties the queue (end of a process that wants its
+        memory back: a parked exec keeps its private pool, ~23 GB for ResNet-50 at batch 64)."""
         graphs = self._all_graphs()
         if graphs and torch.cuda.is_available():
             torch.cuda.synchronize()
-        if os.environ.get("YV1_GRAPH_DEFER_DESTROY"):          # diagnosis only: park the execs instead of destroying them
-            GraphedStep._PARKED.extend(graphs)
-        else:
-            for g in graphs:
-                g.reset()
+        GraphedStep._PARKED.extend(graphs)
+        GraphedStep.drain(keep=max(0, GraphedStep.PARK))
         self.graphs, self.graph, self.graph2 = [], None, None
         self.loss = None
         self.phases, self.phase1 = [], None
