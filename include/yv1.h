@@ -261,8 +261,8 @@ int yv1_bn3_dw(const float* T, const float* G, const float* sz_partials, int row
  * gradient tensor is never stored.  1x1, stride 1, pad 0; Cout (the convolution's output channels) % 64 == 0. */
 int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin,
                                            int Cout, int lddy, const void* x, int ldx, const float* scale, const float* shift,
-                                           const float* mean, int accumulate, float* part, yv1_stream_t stream);
-int yv1_conv2d_dgrad_bn_deferred_rows(int M, int Cin, int Cout);
+                                           const float* mean, int accumulate, float* part, int wt_rows, yv1_stream_t stream);
+int yv1_conv2d_dgrad_bn_deferred_rows(int M, int Cin, int Cout, int wt_rows);   /* wt_rows: readable (zero-padded) rows of wt */
 int yv1_bn_bwd_finalize_deferred(const float* part, int rows, int C, float count, const float* gamma, const float* mean,
                                  const float* invstd, float* dgamma, float* dbeta, float* KA, float* KB, int accumulate,
                                  yv1_stream_t stream);   /* rows <= 2048 (yv1_reduce_rows first) */

@@ -115,13 +115,27 @@ __global__ void __launch_bounds__(256) k_bn3_dw(const float* __restrict__ T, con
                                                 int C4, const float* __restrict__ k1, const float* __restrict__ k2,
                                                 const float* __restrict__ k3is, const float* __restrict__ mean,
                                                 float* __restrict__ dW) {
-  __shared__ float sa[32][33], sb[32][33], ssz[32];
+  __shared__ float sa[32][33], sb[32][33], ssz[32], sred[8][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  if (ty == 0) {
-    float t = 0.f;
-    for (int r = 0; r < rows; ++r) t += szp[(size_t)r * 2 * p + j0 + tx];
-    ssz[tx] = t;
+  {
+    // column sums of the partial rows: eight row lanes per column, two loads in flight each, combined in a fixed order (one
+    // serial chain per column over ~1000 rows took 200 us per launch: the whole kernel was this loop)
+    float t0 = 0.f, t1 = 0.f;
+    int r = ty;
+    for (; r + 8 < rows; r += 16) {
+      t0 += szp[(size_t)r * 2 * p + j0 + tx];
+      t1 += szp[(size_t)(r + 8) * 2 * p + j0 + tx];
+    }
+    if (r < rows) t0 += szp[(size_t)r * 2 * p + j0 + tx];
+    sred[ty][tx] = t0 + t1;
+    __syncthreads();
+    if (ty == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += sred[i][tx];
+      ssz[tx] = t;
+    }
   }
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i0 = 0; i0 < p; i0 += 32) {

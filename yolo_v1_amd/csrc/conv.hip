@@ -79,6 +79,7 @@ struct ConvArgs {
   const float* dbshift = nullptr;
   const float* dbmean = nullptr;
   float* dbpart = nullptr;             // [MT][2][Cout]: sum(d), sum(d * (x - mean)) with d = masked gradient (bf16 values)
+  int db_wt_rows = 0;                  // readable rows of W (zero beyond Cout): lets the last column tile reach past Cout
   int M;
   int MT, NT;
   int slots = 0;       // k_conv_ps: workgroups per column tile; workgroup (slot, nt) walks the pixel tiles slot, slot+slots, ...
@@ -185,10 +186,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     static_assert(NTH % OCPR == 0, "a thread keeps its channel chunk across the store passes");
     constexpr int RG = NTH / OCPR;
     const int cc = tid % OCPR, rg = tid / OCPR;
+    const bool cok = n0 + cc * 8 < a.Cout;                 // the last column tile may reach past Cout (zero weight rows)
     float sc[8], sh[8], mu[8], s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      sc[k] = a.dbscale[n0 + cc * 8 + k]; sh[k] = a.dbshift[n0 + cc * 8 + k]; mu[k] = a.dbmean[n0 + cc * 8 + k];
+      sc[k] = cok ? a.dbscale[n0 + cc * 8 + k] : 0.f; sh[k] = cok ? a.dbshift[n0 + cc * 8 + k] : 0.f;
+      mu[k] = cok ? a.dbmean[n0 + cc * 8 + k] : 0.f;
       s1[k] = 0.f; s2[k] = 0.f;
     }
     uint4 x_pre[OPASSES], old_pre[OPASSES];
@@ -196,7 +199,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     for (int i = 0; i < OPASSES; ++i) {
       const int row = rg + i * RG, m = m0 + row;
       x_pre[i] = make_uint4(0u, 0u, 0u, 0u); old_pre[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (row < BM && m < a.M) {
+      if (cok && row < BM && m < a.M) {
         x_pre[i] = *reinterpret_cast<const uint4*>(a.DBX + (size_t)m * a.lddbx + n0 + cc * 8);
         if (a.accumulate) old_pre[i] = *reinterpret_cast<const uint4*>(a.Y + (size_t)m * a.ldy + n0 + cc * 8);
       }
@@ -204,7 +207,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
 #pragma unroll
     for (int i = 0; i < OPASSES; ++i) {
       const int row = rg + i * RG, m = m0 + row;
-      if (row < BM && m < a.M) {
+      if (cok && row < BM && m < a.M) {
         const uint4 v = *reinterpret_cast<const uint4*>(et + row * EPI_PITCH + cc * 16);
         const unsigned* pv = reinterpret_cast<const unsigned*>(&v);
         const unsigned* px = reinterpret_cast<const unsigned*>(&x_pre[i]);
@@ -230,7 +233,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
 #pragma unroll
     for (int k = 0; k < 8; ++k) { r1[rg * BN + cc * 8 + k] = s1[k]; r2[rg * BN + cc * 8 + k] = s2[k]; }
     __syncthreads();
-    if (tid < BN) {
+    if (tid < BN && n0 + tid < a.Cout) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll 8
       for (int r = 0; r < RG; ++r) { t1 += r1[r * BN + tid]; t2 += r2[r * BN + tid]; }
@@ -1580,7 +1583,7 @@ int launch_dma(ConvArgs& a, hipStream_t stream) {
   constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
   static_assert(!DB || LDS >= (size_t)2 * 8 * WM * WN * 64 * 4, "the deferred-BatchNorm sums reduce through 2 x [RG][BN] floats");
   a.MT = (a.M + BM - 1) / BM;
-  a.NT = a.Cout / BN;
+  a.NT = DB ? (a.Cout + BN - 1) / BN : a.Cout / BN;       // DB: a partial last column tile (guarded epilogue, zero weight rows)
   auto kern = k_conv_dma<BM, BN, BK, WM, WN, NST, DB>;
   if (LDS > 64 * 1024) YV1_SET_MAX_LDS(kern, LDS);
   {
@@ -1764,10 +1767,18 @@ ConvPlan plan_conv(int M, int Cout, int Cin, int taps, bool s1p1 = false) {
 }
 
 // tile of a deferred-BatchNorm data gradient (1x1, K = Cin a multiple of 64): choose_cfg's tile, the ring depth fixed per tile
-ConvPlan plan_deferred(int M, int Cout, int Cin) {
+// wt_rows: rows of the weight operand that may be read (>= Cout; zero beyond Cout).  Cout = 64j + 32 (every other DenseNet
+// layer) would otherwise run 32-wide tiles -- 99 us per launch against 67-72 for the 64 / 128-wide ones, the gradient
+// operand re-read Cout/32 times: with padded weights the last column tile simply reaches past Cout (guarded epilogue).
+ConvPlan plan_deferred(int M, int Cout, int Cin, int wt_rows) {
   ConvPlan p;
   p.kind = 1;
-  p.bm = choose_cfg(M, Cout, Cin, &p.bn);
+  int cr = Cout;
+  if (Cout % 64 == 32 && Cout > 32) {
+    const int c128 = (Cout + 127) / 128 * 128, c64 = (Cout + 63) / 64 * 64;
+    cr = (Cout % 128 == 96 && wt_rows >= c128) ? c128 : (wt_rows >= c64 ? c64 : Cout);
+  }
+  p.bm = choose_cfg(M, cr, Cin, &p.bn);
   p.bk = (p.bn == 32 || p.bm == 64) ? 64 : 32;
   p.nst = 3;
   return p;
@@ -1820,7 +1831,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     // deferred BatchNorm backward: a 1x1 stride-1 data gradient through k_conv_dma<..., DB = true>, one tile per workgroup
     // (yv1_conv2d_dgrad_bn_deferred_rows() = its pixel tiles)
     if (a.R * a.S != 1 || a.os != 1 || a.AS || a.OM || a.gsum || a.X2 || a.stats || a.escale || a.ERES) return YV1_ERR_UNSUPPORTED;
-    p = plan_deferred(a.M, a.Cout, a.Cin);
+    p = plan_deferred(a.M, a.Cout, a.Cin, a.db_wt_rows);
     if (p.bm == 128 && p.bn == 128) return launch_dma<128, 128, 32, 2, 2, 3, true>(a, stream);
     if (p.bm == 128 && p.bn == 64) return launch_dma<128, 64, 32, 2, 2, 3, true>(a, stream);
     if (p.bm == 64 && p.bn == 64) return launch_dma<64, 64, 64, 2, 2, 3, true>(a, stream);
@@ -2095,12 +2106,14 @@ extern "C" int yv1_conv2d_dgrad_out_nhwc_bf16(const void* dy, const void* wt, vo
 // gradient of those channels is consumed.  The stand-alone reduce and apply passes and the stored d tensor disappear.
 // x: the BatchNorm input [N,IH,IW,*] (pixel stride ldx), scale/shift/mean: its forward coefficients [Cin]; Cout (the
 // convolution's output channels = GEMM K) must be a multiple of 64.  part: [yv1_conv2d_dgrad_bn_deferred_rows()][2][Cin].
+// wt_rows: rows of wt ([wt_rows][Cout] bf16) that may be read, >= Cin and ZERO beyond Cin -- padded to a multiple of 128 the
+// Cin = 64j + 32 layers run 64- / 128-wide column tiles whose last tile reaches past Cin.
 extern "C" int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx,
                                                       int Cin, int Cout, int lddy, const void* x, int ldx, const float* scale,
                                                       const float* shift, const float* mean, int accumulate, float* part,
-                                                      hipStream_t stream) {
+                                                      int wt_rows, hipStream_t stream) {
   yv1_cfg_reset();
-  if (!dy || !wt || !dx || !x || !scale || !shift || !mean || !part || N <= 0) return YV1_ERR_BAD_ARG;
+  if (!dy || !wt || !dx || !x || !scale || !shift || !mean || !part || N <= 0 || wt_rows < Cin) return YV1_ERR_BAD_ARG;
   if (Cout % 64 || Cin % 32 || ldx % 8 || lddx % 8) return YV1_ERR_UNSUPPORTED;
   ConvArgs a;
   a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx;
@@ -2112,12 +2125,13 @@ extern "C" int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void
   a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
   a.M = N * IH * IW;
   a.DBX = (const bf16_t*)x; a.lddbx = ldx; a.dbscale = scale; a.dbshift = shift; a.dbmean = mean; a.dbpart = part;
+  a.db_wt_rows = wt_rows;
   return dispatch(a, stream);
 }
 
 // partial rows of yv1_conv2d_dgrad_bn_deferred_nhwc_bf16's sums: one per pixel tile of the kernel it dispatches
-extern "C" int yv1_conv2d_dgrad_bn_deferred_rows(int M, int Cin, int Cout) {
-  const ConvPlan p = plan_deferred(M, Cin, Cout);
+extern "C" int yv1_conv2d_dgrad_bn_deferred_rows(int M, int Cin, int Cout, int wt_rows) {
+  const ConvPlan p = plan_deferred(M, Cin, Cout, wt_rows);
   return (M + p.bm - 1) / p.bm;
 }
 

@@ -51,6 +51,15 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+def _new_tr(Ipad, taps, Opad, dev):
+    """Transposed weight copy [Ipad][taps][Opad]; pointwise weights get their rows padded to a multiple of 128 with zeros
+    (never rewritten: the prep kernels fill the first Ipad rows) so that a data-gradient column tile may reach past Ipad
+    (conv_dgrad_bn_deferred)."""
+    if taps != 1 or Ipad % 128 == 0:
+        return torch.empty((Ipad, taps, Opad), dtype=torch.bfloat16, device=dev)
+    return torch.zeros(((Ipad + 127) // 128 * 128, taps, Opad), dtype=torch.bfloat16, device=dev)
+
+
 class ConvWeights:
     """bf16 shadow copies of one fp32 OIHW parameter, refreshed when the parameter changes:
     ``fwd`` [Opad][taps][Ipad] and ``tr`` [Ipad][taps][Opad] (dgrad operand)."""
@@ -84,7 +93,7 @@ class ConvWeights:
             taps = self.k * self.k
             if self.fwd is None or self.fwd.device != dev:
                 self.fwd = torch.empty((self.Opad, taps, self.Ipad), dtype=torch.bfloat16, device=dev)
-                self.tr = torch.empty((self.Ipad, taps, self.Opad), dtype=torch.bfloat16, device=dev) if self.need_dgrad else None
+                self.tr = _new_tr(self.Ipad, taps, self.Opad, dev) if self.need_dgrad else None
             check(lib().yv1_prep_weights(ptr(src), so, si, sh, sw, self.O, self.I, self.k, self.k, self.Opad, self.Ipad,
                                          ptr(self.fwd), ptr(self.tr), s), "yv1_prep_weights")
         self.version = ver
@@ -107,7 +116,7 @@ def refresh_many(weights):
         taps = w.k * w.k
         if w.fwd is None or w.fwd.device != dev:
             w.fwd = torch.empty((w.Opad, taps, w.Ipad), dtype=torch.bfloat16, device=dev)
-            w.tr = torch.empty((w.Ipad, taps, w.Opad), dtype=torch.bfloat16, device=dev) if w.need_dgrad else None
+            w.tr = _new_tr(w.Ipad, taps, w.Opad, dev) if w.need_dgrad else None
         stale.append((w, ver))
     if not stale:
         return
@@ -449,14 +458,20 @@ def bn3_algebra_backward(gm, gsum, z2, w3, st3, bn3, conv3_param, dz2, side, str
     gbuf = wgrad_raw_buffers(z2, z2)
     srows = L.yv1_bn_reduce_rows(z2.npix, p)
     szp = _f32(srows * 2 * p, dev).view(srows, 2, p)
+    # long partial tables are pre-reduced to <= 32 rows (coalesced, parallel): the dW kernel sums them per 32x32 tile
+    RB = (srows + 31) // 32
+    srows2 = (srows + RB - 1) // RB if srows > 64 else srows
+    szp2 = _f32(srows2 * 2 * p, dev) if srows > 64 else szp
 
     def weight_side():
         overl = side.side is not None and not getattr(side, "wide", False)
         G, _ = wgrad_raw(z2, z2, shared=overl, buffers=gbuf)
         check(L.yv1_bn_stats(z2.p, z2.ld, z2.npix, p, ptr(szp), stream_ptr(dev)), "yv1_bn_stats")
-        check(L.yv1_bn3_dw(ptr(T), ptr(G), ptr(szp), srows, ptr(w3.fwd), p, C4, ptr(kk[0]), ptr(kk[1]), ptr(kk[2]),
+        if szp2 is not szp:
+            check(L.yv1_reduce_rows(ptr(szp), ptr(szp2), srows, 2 * p, RB, stream_ptr(dev)), "yv1_reduce_rows")
+        check(L.yv1_bn3_dw(ptr(T), ptr(G), ptr(szp2), srows2, ptr(w3.fwd), p, C4, ptr(kk[0]), ptr(kk[1]), ptr(kk[2]),
                            ptr(st3.mean), ptr(dW), stream_ptr(dev)), "yv1_bn3_dw")
-    side.run(weight_side, z2.t, T, ws_t, kk, wcat, bias, dW, gbuf[0], gbuf[1], szp, after=mk)
+    side.run(weight_side, z2.t, T, ws_t, kk, wcat, bias, dW, gbuf[0], gbuf[1], szp, szp2, after=mk)
     if out_mask is not None:
         return dgam, dbet, dW.view(C4, 1, 1, p).permute(0, 3, 1, 2), osum
     return dgam, dbet, dW.view(C4, 1, 1, p).permute(0, 3, 1, 2)
@@ -913,11 +928,13 @@ def conv_dgrad_bn_deferred(dy, w, dx, x, st, accumulate=True):
         raise ValueError("conv_dgrad_bn_deferred: x and dx must be the convolution input's window")
     dev = dy.t.device
     L = lib()
-    rows = L.yv1_conv2d_dgrad_bn_deferred_rows(dx.npix, w.Ipad, w.Opad)
+    wt_rows = w.tr.shape[0]                      # ConvWeights pads the transposed copy of 1x1 weights to 128 rows (zeros)
+    rows = L.yv1_conv2d_dgrad_bn_deferred_rows(dx.npix, w.Ipad, w.Opad, wt_rows)
     part = _f32(rows * 2 * dx.C, dev)
     check(L.yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld, x.p,
                                                    x.ld, ptr(st.scale), ptr(st.shift), ptr(st.mean), 1 if accumulate else 0,
-                                                   ptr(part), stream_ptr(dev)), "yv1_conv2d_dgrad_bn_deferred_nhwc_bf16")
+                                                   ptr(part), wt_rows, stream_ptr(dev)),
+          "yv1_conv2d_dgrad_bn_deferred_nhwc_bf16")
     return part.view(rows, 2, dx.C)
 
 
