@@ -43,7 +43,9 @@ def _setup(N, H, cin, cout, seed):
 
 
 @pytest.mark.parametrize("N,H,cin,cout,accumulate", [
-    (4, 28, 160, 128, True),       # 128x32 tiles (cin % 64 != 0)
+    (4, 28, 160, 128, True),       # cin = 64j + 32: 64-wide tiles whose last column tile reaches past cin (zero weight rows)
+    (4, 28, 224, 128, True),       # cin % 128 == 96: 128- or 64-wide tiles, last one a quarter empty
+    (4, 28, -160, 128, True),      # the same with UNPADDED transposed weights: the 128x32 fallback
     (2, 56, 64, 128, True),        # 64-wide tiles
     (8, 28, 256, 128, True),       # 128x128 tiles
     (3, 14, 320, 128, True),       # 64x64 tiles (few tiles)
@@ -59,7 +61,10 @@ def _setup(N, H, cin, cout, seed):
 ])
 def test_deferred_data_gradient_against_dgrad_plus_bn_backward(N, H, cin, cout, accumulate):
     from yolo_v1_amd import _lib, ops
+    unpadded, cin = cin < 0, abs(cin)
     x, bn, st, w, dy, old = _setup(N, H, cin, cout, 7 * cin + H)
+    if unpadded:
+        w.tr = w.tr[:w.Ipad].clone()
     # reference
     G_ref = ops.Act(old.clone() if accumulate else torch.empty_like(old))
     dt = ops.new_act(N, H, H, cin, DEV)
@@ -75,6 +80,7 @@ def test_deferred_data_gradient_against_dgrad_plus_bn_backward(N, H, cin, cout, 
     torch.cuda.synchronize()
     print("\n%s  rows %d" % (cfg, part.shape[0]))
     assert "bn-deferred" in cfg and "k_conv_dma<" in cfg
+    assert ("k_conv_dma<128,32," in cfg) == unpadded, cfg
     sb = float(db_ref.abs().max()) + 1e-12
     sg = float(dg_ref.abs().max()) + 1e-12
     assert float((db - db_ref).abs().max()) <= 1e-4 * sb, float((db - db_ref).abs().max()) / sb
