@@ -268,6 +268,17 @@ int yv1_bn_bwd_finalize_deferred(const float* part, int rows, int C, float count
                                  yv1_stream_t stream);   /* rows <= 2048 (yv1_reduce_rows first) */
 int yv1_bn_deferred_fix(void* g, int ldg, const void* x, int ldx, const float* KA, const float* KB, long long npix, int C,
                         yv1_stream_t stream);            /* g -= KA + KB * x over a C-channel window */
+/* The reduction pass of a BatchNorm(+ReLU) backward folded into the epilogue of the data gradient that PRODUCES its input
+ * gradient (round 3; the mirror image of the forward's statistics epilogue): for a stride-1 k x k convolution whose input was
+ * relu(bn(y)) -- conv2 after bn1 / conv3 after bn2 of a Bottleneck (OriginResNet.py:90-99), conv2 after norm2 of a _DenseLayer
+ * (OriginDenseNet.py:26-31) -- dx is stored MASKED (scale*y + shift > 0) and part gets yv1_bn_bwd_reduce's layout
+ * [rows][2][Cin] = sum d, sum d*xhat per pixel tile; yv1_bn_bwd_finalize + yv1_bn_bwd_apply(mask_mode 0) finish the BatchNorm
+ * backward, yv1_bn_bwd_reduce's pass over (dx, y) does not run.  rows() == 0: this shape has no such kernel, keep the passes. */
+int yv1_conv2d_dgrad_bn_sums_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin,
+                                       int Cout, int lddy, int k, int pad, const void* y, int ldy, const float* scale,
+                                       const float* shift, const float* mean, const float* invstd, float* part,
+                                       yv1_stream_t stream);
+int yv1_conv2d_dgrad_bn_sums_rows(int M, int Cin, int Cout, int k, int pad);
 /* BatchNorm(+ReLU) backward behind the stem's 3x3/2 max pool (OriginResNet.py:174-177, OriginDenseNet.py:120-128; autograd
  * of nn.MaxPool2d + nn.ReLU + nn.BatchNorm2d): dpool [N,OH,OW,C] is the gradient of the pool OUTPUT, pool_idx what
  * yv1_maxpool3x3s2_fwd stored; the pool's backward is gathered on the fly, so the 4x larger gradient of the pool input is

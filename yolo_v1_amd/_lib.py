@@ -67,6 +67,9 @@ SIGNATURES = {
     "yv1_conv2d_dgrad_bn_deferred_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p,
                                                      c_i, c_p, c_i, c_p]),
     "yv1_conv2d_dgrad_bn_deferred_rows": (c_i, [c_i, c_i, c_i, c_i]),
+    "yv1_conv2d_dgrad_bn_sums_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p,
+                                                 c_p, c_p, c_p]),
+    "yv1_conv2d_dgrad_bn_sums_rows": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     # bn_deferred.hip
     "yv1_bn_bwd_finalize_deferred": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "yv1_bn_deferred_fix": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_ll, c_i, c_p]),

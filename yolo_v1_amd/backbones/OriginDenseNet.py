@@ -131,10 +131,15 @@ class DenseNet(HipBackbone):
             ops.bn_deferred_fix(dy2, buf.window(cin, self.growth), K[:, cin:cin + self.growth])
         mk = side.mark()
         dt2 = ops.new_act(N, t2.H, t2.W, t2.C, dev)
-        ops.conv_dgrad(dy2, w2, dt2)
+        part2 = ops.conv_dgrad_bn_sums(dy2, w2, dt2, y1, st2)     # norm2's reduction pass inside conv2's data gradient
+        if part2 is None:
+            ops.conv_dgrad(dy2, w2, dt2)
         grads[layer.conv2.weight] = ops.conv_wgrad(t2, dy2, w2, side, after=mk)
         dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
-        grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward(dt2, y1, st2, layer.norm2, dy1, 2)
+        if part2 is None:
+            grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward(dt2, y1, st2, layer.norm2, dy1, 2)
+        else:
+            grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward_from_sums(dt2, y1, st2, layer.norm2, dy1, part2)
         mk = side.mark()
         if K is not None:
             part = ops.conv_dgrad_bn_deferred(dy1, w1, G.window(0, cin), buf.window(0, cin), st1, accumulate=True)

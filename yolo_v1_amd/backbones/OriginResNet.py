@@ -244,6 +244,7 @@ class ResNet(HipBackbone):
         g_in = ops.new_act(N, x.H, x.W, x.C, dev)
         algebra = g_sum is not None
         dz2 = ops.new_act(N, z2.H, z2.W, z2.C, dev)
+        part2 = None
         if algebra:
             # bn3's reduce / finalize / apply passes and conv3's ordinary dgrad + wgrad, as four GEMM-side steps
             (grads[blk.bn3.weight], grads[blk.bn3.bias], grads[blk.conv3.weight]) = ops.bn3_algebra_backward(
@@ -276,18 +277,29 @@ class ResNet(HipBackbone):
             # main-chain kernel pushes the main chain onto a new queue -- after four such forks (the projection blocks) it
             # wrapped around onto the weight gradients' queue and layer2's backward ran serialized with them
             mk = side.mark()
-            ops.conv_dgrad(dy3, w3, dz2)
+            # bn2's reduction pass rides in conv3's data gradient where that shape has the epilogue (ops.conv_dgrad_bn_sums)
+            part2 = ops.conv_dgrad_bn_sums(dy3, w3, dz2, y2, s2) if self.bn_sums_conv3 else None
+            if part2 is None:
+                ops.conv_dgrad(dy3, w3, dz2)
             if yd is not None:
                 grads[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, wd, side, after=mk)
             grads[blk.conv3.weight] = ops.conv_wgrad(z2, dy3, w3, side, after=mk)
         dy2 = ops.new_act(N, y2.H, y2.W, y2.C, dev)
-        grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
+        if part2 is None:
+            grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward(dz2, y2, s2, blk.bn2, dy2, 2)
+        else:
+            grads[blk.bn2.weight], grads[blk.bn2.bias] = ops.bn_backward_from_sums(dz2, y2, s2, blk.bn2, dy2, part2)
         mk = side.mark()
         dz1 = ops.new_act(N, z1.H, z1.W, z1.C, dev)
-        ops.conv_dgrad(dy2, w2, dz1)
+        part1 = ops.conv_dgrad_bn_sums(dy2, w2, dz1, y1, s1) if self.bn_sums_conv2 else None   # (engine.py: off by default)
+        if part1 is None:
+            ops.conv_dgrad(dy2, w2, dz1)
         grads[blk.conv2.weight] = ops.conv_wgrad(z1, dy2, w2, side, after=mk)
         dy1 = ops.new_act(N, y1.H, y1.W, y1.C, dev)
-        grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
+        if part1 is None:
+            grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward(dz1, y1, s1, blk.bn1, dy1, 2)
+        else:
+            grads[blk.bn1.weight], grads[blk.bn1.bias] = ops.bn_backward_from_sums(dz1, y1, s1, blk.bn1, dy1, part1)
         mk = side.mark()
         sums = None
         if yd is not None and algebra:

@@ -80,6 +80,8 @@ struct ConvArgs {
   const float* dbmean = nullptr;
   float* dbpart = nullptr;             // [MT][2][Cout]: sum(d), sum(d * (x - mean)) with d = masked gradient (bf16 values)
   int db_wt_rows = 0;                  // readable rows of W (zero beyond Cout): lets the last column tile reach past Cout
+  int db_unit = 0;                     // 1: store the masked gradient itself (not scale * masked): the BatchNorm backward's
+  const float* dbis = nullptr;         //    apply pass follows; dbis: invstd -- the second sum is then sum(d * xhat)
   int M;
   int MT, NT;
   int slots = 0;       // k_conv_ps: workgroups per column tile; workgroup (slot, nt) walks the pixel tiles slot, slot+slots, ...
@@ -220,8 +222,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
           const float dh = (xh * sc[2 * k + 1] + sh[2 * k + 1]) > 0.f ? __uint_as_float(pv[k] & 0xffff0000u) : 0.f;
           s1[2 * k] += dl; s1[2 * k + 1] += dh;
           s2[2 * k] += dl * (xl - mu[2 * k]); s2[2 * k + 1] += dh * (xh - mu[2 * k + 1]);
-          res[k] = pack_bf16x2(__uint_as_float(po[k] << 16) + sc[2 * k] * dl,
-                               __uint_as_float(po[k] & 0xffff0000u) + sc[2 * k + 1] * dh);
+          res[k] = pack_bf16x2(__uint_as_float(po[k] << 16) + (a.db_unit ? dl : sc[2 * k] * dl),
+                               __uint_as_float(po[k] & 0xffff0000u) + (a.db_unit ? dh : sc[2 * k + 1] * dh));
         }
         *reinterpret_cast<uint4*>(a.Y + (size_t)m * a.ldy + n0 + cc * 8) = make_uint4(res[0], res[1], res[2], res[3]);
       }
@@ -239,7 +241,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
       for (int r = 0; r < RG; ++r) { t1 += r1[r * BN + tid]; t2 += r2[r * BN + tid]; }
       float* o = a.dbpart + (size_t)mt * 2 * a.Cout + n0 + tid;
       o[0] = t1;
-      o[a.Cout] = t2;
+      o[a.Cout] = a.dbis ? t2 * a.dbis[n0 + tid] : t2;
     }
     return;
   }
@@ -785,7 +787,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128
 //   * dgrad of the same geometry is the forward of the flipped filter: `flip` maps loop tap (r, s) to weight tap
 //     (2-r, 2-s) of the transposed copy.
 // One tile per workgroup, k_conv_dma's ring and the shared epilogue.
-template <int BM, int BN, int BK, int WM, int WN, int NST>
+template <int BM, int BN, int BK, int WM, int WN, int NST, bool DB = false>
 __global__ void __launch_bounds__(256, ((BM + 64 / (BK / 8)) * BK * 2 + 3 * BN * BK * 2) * NST <= 53 * 1024 ? 3 : (((BM + 64 / (BK / 8)) * BK * 2 + 3 * BN * BK * 2) * NST <= 80 * 1024 ? 2 : 1))
 k_conv_h3(ConvArgs a, int flip) {
   constexpr int NTH = 256;
@@ -971,7 +973,7 @@ k_conv_h3(ConvArgs a, int flip) {
 #undef YV1_ISSUE_H
 #undef YV1_WAIT_H
   __syncthreads();
-  conv_epilogue<BM, BN, WM, WN>(acc, a, smem, m0, n0, mt);
+  conv_epilogue<BM, BN, WM, WN, DB>(acc, a, smem, m0, n0, mt);
 }
 
 // off ^ (ks << 5), computed where it is used: volatile asm so that the compiler does not hoist the KS variants of every
@@ -1589,26 +1591,27 @@ int launch_dma(ConvArgs& a, hipStream_t stream) {
   {
     const bool direct = a.R * a.S == 1 && a.ah == 1 && a.aw == 1 && a.ch == 0 && a.cw == 0 && a.log2d == 0 &&
                         a.P == a.IH && a.Q == a.IW;         // the kernel's own condition for its direct addressing
-    yv1_cfg_note("k_conv_dma<%d,%d,%d,%d,%d,%d>%s%s", BM, BN, BK, WM, WN, NST, direct ? " direct" : "", DB ? " bn-deferred" : "");
+    yv1_cfg_note("k_conv_dma<%d,%d,%d,%d,%d,%d>%s%s", BM, BN, BK, WM, WN, NST, direct ? " direct" : "", DB ? (a.db_unit ? " bn-sums" : " bn-deferred") : "");
   }
   hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(WM * WN * 64), LDS, stream, a);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NST>
+template <int BM, int BN, int BK, int WM, int WN, int NST, bool DB = false>
 int launch_h3(ConvArgs& a, hipStream_t stream) {
   constexpr int CPR = BK / 8;
   constexpr int STAGE = (BM + 64 / CPR) * BK * 2 + 3 * BN * BK * 2;
   constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
   constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
   constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
+  static_assert(!DB || LDS >= (size_t)2 * 8 * 256 * 4, "the BatchNorm-backward sums reduce through 2 x [RG][BN] floats");
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
-  auto kern = k_conv_h3<BM, BN, BK, WM, WN, NST>;
+  auto kern = k_conv_h3<BM, BN, BK, WM, WN, NST, DB>;
   if (LDS > 64 * 1024) YV1_SET_MAX_LDS(kern, LDS);
   const int flip = a.bh < 0 ? 1 : 0;
-  yv1_cfg_note("k_conv_h3<%d,%d,%d,%d,%d,%d>%s", BM, BN, BK, WM, WN, NST, flip ? " flipped" : "");
+  yv1_cfg_note("k_conv_h3<%d,%d,%d,%d,%d,%d>%s%s", BM, BN, BK, WM, WN, NST, flip ? " flipped" : "", DB ? " bn-sums" : "");
   hipLaunchKernelGGL(kern, dim3(a.MT * a.NT), dim3(256), LDS, stream, a, flip);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
@@ -1784,6 +1787,26 @@ ConvPlan plan_deferred(int M, int Cout, int Cin, int wt_rows) {
   return p;
 }
 
+// Kernel of a data gradient with the BatchNorm-backward epilogue: the pointwise form (plan_deferred), k_conv_h3 where the
+// plain data gradient would run it (3x3 stride 1 with a 64-channel K block), else k_conv_dma with the 32-channel K step and
+// the three-stage ring -- the DB instantiations.  kind 0: not available for this shape (the caller keeps the separate passes).
+ConvPlan plan_db(int M, int Cout, int Cin, int taps, bool s1p1, int wt_rows) {
+  if (taps == 1) return plan_deferred(M, Cout, Cin, wt_rows);
+  ConvPlan q = plan_conv(M, Cout, Cin, taps, s1p1);
+  ConvPlan p;
+  p.kind = 0; p.bm = q.bm; p.bn = q.bn; p.bk = 32; p.nst = 3;
+  if (q.kind == 3) {
+    if (q.bm == 128 && q.bk == 32 && (q.bn == 128 || q.bn == 64)) { p.kind = 3; p.nst = 2; }
+    return p;
+  }
+  if (q.bn == 256 || q.bm == 256) return p;              // the 256-wide / 256x256 tiles have no DB form
+  if (Cin % 64 && q.bn == 32) return p;                  // 128x32 needs the 64-channel K step
+  p.kind = 1;
+  p.bk = (q.bn == 32 || q.bm == 64) ? 64 : 32;
+  if (p.bk == 64 && Cin % 64) p.kind = 0;
+  return p;
+}
+
 // every (tile, K-step, stage count) the ring kernels are instantiated for
 #define YV1_RING_CASES                 \
   YV1_RING_CASE(128, 256, 32, 2, 2, 3) \
@@ -1809,6 +1832,23 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     if (dbg < 0) dbg = env_int("YV1_CONV_DBG", 0);
     a.dbg = dbg;
   }
+  if (a.DBX) {
+    // BatchNorm-backward epilogue (ConvArgs::DBX), one tile per workgroup: yv1_conv2d_dgrad_bn_deferred_rows() /
+    // yv1_conv2d_dgrad_bn_sums_rows() = its pixel tiles.  k_conv_dma<..., DB = true> (any stride-1 geometry) or k_conv_h3<..., DB>
+    if (a.os != 1 || a.AS || a.OM || a.gsum || a.X2 || a.stats || a.escale || a.ERES) return YV1_ERR_UNSUPPORTED;
+    ConvPlan p = plan_db(a.M, a.Cout, a.Cin, a.R * a.S, is_s1p1_3x3(a), a.db_wt_rows);
+    if (p.kind == 3) {
+      if (p.bn == 128) return launch_h3<128, 128, 32, 2, 2, 2, true>(a, stream);
+      if (p.bn == 64) return launch_h3<128, 64, 32, 2, 2, 2, true>(a, stream);
+      return YV1_ERR_UNSUPPORTED;
+    }
+    if (p.kind != 1) return YV1_ERR_UNSUPPORTED;
+    if (p.bm == 128 && p.bn == 128) return launch_dma<128, 128, 32, 2, 2, 3, true>(a, stream);
+    if (p.bm == 128 && p.bn == 64) return launch_dma<128, 64, 32, 2, 2, 3, true>(a, stream);
+    if (p.bm == 64 && p.bn == 64) return launch_dma<64, 64, 64, 2, 2, 3, true>(a, stream);
+    if (p.bm == 128 && p.bn == 32) return launch_dma<128, 32, 64, 4, 1, 3, true>(a, stream);
+    return YV1_ERR_UNSUPPORTED;
+  }
   ConvPlan p = plan_conv(a.M, a.Cout, a.Cin, a.R * a.S, is_s1p1_3x3(a));
   if (p.kind == 3) {
 #define YV1_H3_CASE(BN_, BK_, WM_, WN_)                                                                          \
@@ -1827,17 +1867,6 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
   static int as_min_m = -1;
   if (as_min_m < 0) as_min_m = env_int("YV1_AS_DMA_MIN_M", 0);
   if (p.kind == 2 && a.AS && a.M >= as_min_m) p.kind = 1;
-  if (a.DBX) {
-    // deferred BatchNorm backward: a 1x1 stride-1 data gradient through k_conv_dma<..., DB = true>, one tile per workgroup
-    // (yv1_conv2d_dgrad_bn_deferred_rows() = its pixel tiles)
-    if (a.R * a.S != 1 || a.os != 1 || a.AS || a.OM || a.gsum || a.X2 || a.stats || a.escale || a.ERES) return YV1_ERR_UNSUPPORTED;
-    p = plan_deferred(a.M, a.Cout, a.Cin, a.db_wt_rows);
-    if (p.bm == 128 && p.bn == 128) return launch_dma<128, 128, 32, 2, 2, 3, true>(a, stream);
-    if (p.bm == 128 && p.bn == 64) return launch_dma<128, 64, 32, 2, 2, 3, true>(a, stream);
-    if (p.bm == 64 && p.bn == 64) return launch_dma<64, 64, 64, 2, 2, 3, true>(a, stream);
-    if (p.bm == 128 && p.bn == 32) return launch_dma<128, 32, 64, 4, 1, 3, true>(a, stream);
-    return YV1_ERR_UNSUPPORTED;
-  }
   if (p.kind == 2 && (a.X2 || a.OM || a.gsum)) p.kind = 1;       // second K source / output mask / column sums: k_conv_dma only
   if (p.kind == 0 && (a.X2 || a.OM || a.gsum)) return YV1_ERR_UNSUPPORTED;
   if (p.kind == 0) {
@@ -2132,6 +2161,46 @@ extern "C" int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void
 // partial rows of yv1_conv2d_dgrad_bn_deferred_nhwc_bf16's sums: one per pixel tile of the kernel it dispatches
 extern "C" int yv1_conv2d_dgrad_bn_deferred_rows(int M, int Cin, int Cout, int wt_rows) {
   const ConvPlan p = plan_deferred(M, Cin, Cout, wt_rows);
+  return (M + p.bm - 1) / p.bm;
+}
+
+// Data gradient of a STRIDE-1 convolution (k x k, pad) whose input was relu(bn(y)), with the reduction pass of that
+// BatchNorm's backward folded into the epilogue -- the mirror image of the forward's statistics epilogue:
+//     dx = bf16(dgrad(dy, wt)) where scale*y + shift > 0, else 0        (the MASKED gradient d, stored)
+//     part[tile][0][c] = sum d,   part[tile][1][c] = invstd[c] * sum d * (y - mean[c])  = sum d * xhat
+// part has the layout yv1_bn_bwd_reduce writes, so yv1_bn_bwd_finalize + yv1_bn_bwd_apply (mask_mode 0: d is masked
+// already) complete the BatchNorm backward; yv1_bn_bwd_reduce's pass over (dx, y) does not run.  Returns
+// YV1_ERR_UNSUPPORTED for shapes whose plain data gradient runs a kernel without this epilogue (stride 2, the 256-wide tiles):
+// yv1_conv2d_dgrad_bn_sums_rows() returns 0 for them and the caller keeps yv1_conv2d_dgrad_nhwc_bf16 + the reduce pass.
+extern "C" int yv1_conv2d_dgrad_bn_sums_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx,
+                                                  int Cin, int Cout, int lddy, int k, int pad, const void* y, int ldy,
+                                                  const float* scale, const float* shift, const float* mean,
+                                                  const float* invstd, float* part, hipStream_t stream) {
+  yv1_cfg_reset();
+  if (!dy || !wt || !dx || !y || !scale || !shift || !mean || !invstd || !part || N <= 0 || k <= 0) return YV1_ERR_BAD_ARG;
+  if (Cin % 32 || Cout % 32 || ldy % 8 || lddx % 8 || 2 * pad != k - 1) return YV1_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx;
+  a.N = N; a.IH = IH; a.IW = IW; a.ldx = lddy;                  // same-size output: the dy grid is the dx grid
+  a.Cin = Cout; a.Cout = Cin; a.R = k; a.S = k;
+  a.OH = IH; a.OW = IW; a.ldy = lddx; a.accumulate = 0;
+  a.oh0 = a.ow0 = 0; a.wr0 = a.ws0 = 0; a.wrs = a.wss = 1; a.WS = k; a.Kw = k * k * Cout;
+  a.P = IH; a.Q = IW; a.os = 1;
+  if (k == 1) { a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; }
+  else { a.ah = 1; a.bh = -1; a.ch = pad; a.aw = 1; a.bw = -1; a.cw = pad; }
+  a.log2d = 0;
+  a.M = N * IH * IW;
+  a.DBX = (const bf16_t*)y; a.lddbx = ldy; a.dbscale = scale; a.dbshift = shift; a.dbmean = mean; a.dbpart = part;
+  a.db_unit = 1; a.dbis = invstd; a.db_wt_rows = Cin;
+  return dispatch(a, stream);
+}
+
+// partial rows of yv1_conv2d_dgrad_bn_sums_nhwc_bf16 (one per pixel tile), 0 when the shape has no such kernel
+extern "C" int yv1_conv2d_dgrad_bn_sums_rows(int M, int Cin, int Cout, int k, int pad) {
+  if (Cin % 32 || Cout % 32 || 2 * pad != k - 1) return 0;
+  const ConvPlan p = plan_db(M, Cin, Cout, k * k, k == 3 && pad == 1, Cin);
+  if (p.kind != 1 && p.kind != 3) return 0;
+  if (p.kind == 1 && !((p.bm == 128 && (p.bn == 128 || p.bn == 64 || p.bn == 32)) || (p.bm == 64 && p.bn == 64))) return 0;
   return (M + p.bm - 1) / p.bm;
 }
 

@@ -963,6 +963,54 @@ def bn_deferred_fix(g, x, K):
           "yv1_bn_deferred_fix")
 
 
+# the reduction pass of a BatchNorm(+ReLU) backward inside the data gradient that produces its input gradient (0 = separate
+# yv1_bn_bwd_reduce pass)
+BN_SUMS_IN_DGRAD = _os.environ.get("YV1_BN_SUMS_IN_DGRAD", "1") != "0"
+
+
+def conv_dgrad_bn_sums(dy, w, dx, y, st):
+    """dx = mask * conv_transpose(dy, w) with mask = (scale*y + shift > 0) of the TRAINING-mode BatchNorm ``st`` over ``y``
+    (the convolution's input was relu(bn(y))), + the BatchNorm-backward sums of dx per pixel tile.  Returns the partial rows
+    [rows][2][C] for bn_backward_from_sums, or None when this shape has no such kernel (dx untouched: run conv_dgrad +
+    bn_backward instead)."""
+    if not BN_SUMS_IN_DGRAD or w.stride != 1 or 2 * w.pad != w.k - 1:
+        return None
+    if (y.N, y.H, y.W, y.C) != (dx.N, dx.H, dx.W, dx.C):
+        raise ValueError("conv_dgrad_bn_sums: y and dx must have the convolution input's geometry")
+    dev = dy.t.device
+    L = lib()
+    rows = L.yv1_conv2d_dgrad_bn_sums_rows(dx.npix, w.Ipad, w.Opad, w.k, w.pad)
+    if rows <= 0:
+        return None
+    part = _f32(rows * 2 * dx.C, dev)
+    check(L.yv1_conv2d_dgrad_bn_sums_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld, w.k, w.pad,
+                                               y.p, y.ld, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(part),
+                                               stream_ptr(dev)), "yv1_conv2d_dgrad_bn_sums_nhwc_bf16")
+    return part.view(rows, 2, dx.C)
+
+
+def bn_backward_from_sums(d, y, st, bn, dy, part):
+    """BatchNorm(+ReLU) backward from the MASKED gradient ``d`` and its partial sums (conv_dgrad_bn_sums): finalize + apply,
+    no reduction pass.  Returns (dgamma, dbeta)."""
+    dev = y.t.device
+    L = lib()
+    C = y.C
+    rows = part.shape[0]
+    flat, rows = _shrink_partials(part.reshape(-1), rows, 2 * C, dev)
+    gb = torch.empty((5, C), dtype=torch.float32, device=dev)     # dgamma, dbeta, k1, k2, k3
+    dgam, dbet = gb[0], gb[1]
+    if _ARENA[0] is not None and bn is not None and bn.weight.numel() == C:
+        dgam, dbet = _grad_buf(bn.weight, (C,)), _grad_buf(bn.bias, (C,))
+    s = stream_ptr(dev)
+    check(L.yv1_bn_bwd_finalize(ptr(flat), rows, C, float(y.npix), ptr(bn.weight) if bn is not None else None,
+                                ptr(st.invstd), ptr(dgam), ptr(dbet), ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), s),
+          "yv1_bn_bwd_finalize")
+    check(L.yv1_bn_bwd_apply(d.p, d.ld, None, 0, y.p, y.ld, ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
+                             ptr(gb[2]), ptr(gb[3]), ptr(gb[4]), y.npix, C, 0, dy.p, dy.ld, None, 0, 0, s),
+          "yv1_bn_bwd_apply")
+    return dgam, dbet
+
+
 def bn_backward_dual(dz, mask, a, b):
     """BatchNorm backward of TWO BatchNorms that receive the same ReLU-masked gradient (a projection Bottleneck's bn3 and
     downsample BatchNorm, OriginResNet.py:100-105): ``a`` / ``b`` = (y, BNState, bn module, dy).  One reduction pass and
