@@ -279,7 +279,10 @@ def test_multi_tensor_weight_prep_equals_single_tensor_prep():
             ref = torch.zeros(cw_a.Opad, shp[2] * shp[2], cw_a.Ipad)
             ref[:shp[0], :, :shp[1]] = cw_a.param.detach().cpu().permute(0, 2, 3, 1).reshape(shp[0], -1, shp[1])
             assert torch.equal(cw_b.fwd.float().cpu(), ref.to(torch.bfloat16).float())
-            assert torch.equal(cw_b.tr.float().cpu(), ref.permute(2, 1, 0).contiguous().to(torch.bfloat16).float())
+            # pointwise weights: the transposed copy is padded to a multiple of 128 rows, zero beyond Ipad (ops._new_tr)
+            assert cw_b.tr.shape[0] == (cw_b.Ipad if shp[2] != 1 else (cw_b.Ipad + 127) // 128 * 128)
+            assert torch.equal(cw_b.tr[:cw_b.Ipad].float().cpu(), ref.permute(2, 1, 0).contiguous().to(torch.bfloat16).float())
+            assert not bool(cw_b.tr[cw_b.Ipad:].any()) and not bool(cw_a.tr[cw_a.Ipad:].any())
 
 
 def _same_up_to_sum_order(dy_new, dy_ref, dg_new, dg_ref, db_new, db_ref):
