@@ -331,19 +331,35 @@ __device__ __forceinline__ void pooled_grad(const BwdArgs& a, long long p, int c
   const int OH = (int)(H + 2 - 3) / 2 + 1, OW = (int)(W + 2 - 3) / 2 + 1;
 #pragma unroll
   for (int k = 0; k < 8; ++k) g[k] = 0.f;
-  const int oh_lo = h / 2, oh_hi = min(OH - 1, (int)(h + 1) / 2);
-  const int ow_lo = w / 2, ow_hi = min(OW - 1, (int)(w + 1) / 2);
-  for (int oh = oh_lo; oh <= oh_hi; ++oh)
-    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-      const unsigned code = (unsigned)(((int)h - (oh * 2 - 1)) * 3 + ((int)w - (ow * 2 - 1)));
+  // an input pixel lies in one pooled window per axis when its coordinate is even, in two when it is odd: the (up to) four
+  // windows are visited as a fixed 2x2 with predicates -- all index / gradient loads are issued before the first compare
+  // (the loop form with run-time bounds made four dependent round trips to L2 per thread: 1.8 TB/s for the whole kernel)
+  const int oh0 = h / 2, ow0 = w / 2;
+  const bool vh1 = (h & 1u) && oh0 + 1 <= OH - 1, vw1 = (w & 1u) && ow0 + 1 <= OW - 1;
+  uint2 am2[2][2];
+  u32x4 dv[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oh = oh0 + ((i && vh1) ? 1 : 0), ow = ow0 + ((j && vw1) ? 1 : 0);      // clamped: always a valid address
       const size_t o = (size_t)(n * OH + oh) * OW + ow;
-      const uint2 am2 = *reinterpret_cast<const uint2*>(a.pool_idx + o * a.C + c8);
+      am2[i][j] = *reinterpret_cast<const uint2*>(a.pool_idx + o * a.C + c8);
+      dv[i][j] = *reinterpret_cast<const u32x4*>(a.dz + o * a.lddz + c8);
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool valid = (i == 0 || vh1) && (j == 0 || vw1);
+      const int oh = oh0 + i, ow = ow0 + j;
+      const unsigned code = (unsigned)(((int)h - (oh * 2 - 1)) * 3 + ((int)w - (ow * 2 - 1)));
       float d[8];
-      unpack8(*reinterpret_cast<const u32x4*>(a.dz + o * a.lddz + c8), d);
+      unpack8(dv[i][j], d);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const unsigned am = ((k < 4 ? am2.x : am2.y) >> (8 * (k & 3))) & 0xffu;
-        g[k] += am == code ? d[k] : 0.f;
+        const unsigned am = ((k < 4 ? am2[i][j].x : am2[i][j].y) >> (8 * (k & 3))) & 0xffu;
+        g[k] += (valid && am == code) ? d[k] : 0.f;
       }
     }
   // the unfused path stores this gradient as bf16 before the BatchNorm backward reads it: round the same way

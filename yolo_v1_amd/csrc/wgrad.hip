@@ -721,8 +721,10 @@ struct Plan3 { bool use; int kp, spr, total_steps, steps, splitK, KT, CT, bmc; }
 // (serialized backward: 768/512 beat 512/320 by 2.9 % and 1024/768 by 5 %).
 Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad, bool shared) {
   Plan3 p;
-  static int enabled = -1, want_shared = 0, want_alone = 0;
+  static int enabled = -1, want_shared = 0, want_alone = 0, thin_minw = 48;
   if (enabled < 0) {
+    const char* tm = getenv("YV1_WGRAD3_THIN_MINW");  // tuning: narrowest map the thin (Cout 32) multi-tap form takes
+    if (tm && atoi(tm) >= 8) thin_minw = atoi(tm);
     const char* e = getenv("YV1_WGRAD3");            // tuning: 0 disables the multi-tap kernel
     enabled = e ? atoi(e) : 1;
     const char* w = getenv("YV1_WGRAD3_BLOCKS");
@@ -738,7 +740,7 @@ Plan3 make_plan3(int N, int H, int W, int Cin, int Cout, int k, int stride, int 
   const bool square = Cin % 64 == 0 && Cout % 64 == 0 && W >= 24;
   // DenseNet growth convolutions (Cout 32): one 32x128 tile per 128 input channels.  The result is tiny
   // (32x9x128 fp32 = 147 KB per slab), so all the parallelism is split-K: worth it on the wide maps only
-  const bool thin = Cout == 32 && Cin % 128 == 0 && W >= 48;
+  const bool thin = Cout == 32 && Cin % 128 == 0 && W >= thin_minw;
   p.use = enabled && k == 3 && stride == 1 && pad == 1 && (square || thin);
   if (!p.use) return p;
   p.bmc = square ? 64 : 32;
