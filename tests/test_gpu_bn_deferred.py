@@ -93,6 +93,52 @@ def test_deferred_data_gradient_against_dgrad_plus_bn_backward(N, H, cin, cout, 
     assert _rel(a, b) <= 5e-3, _rel(a, b)
 
 
+def test_every_densenet121_layer_shape_at_batch_64():
+    """Every norm1 -> conv1 of DenseNet-121 at 448x448, batch 64 (58 dense layers: cin = 64 + 32 i at 112^2, 128 + 32 i at
+    56^2, 256 + 32 i at 28^2, 512 + 32 i at 14^2) and its four transitions through the deferred data gradient, against
+    dgrad + the three BatchNorm-backward passes.  Device-side random operands (the point is the tile / guard logic of every
+    channel count the step runs: 128-, 64- and 32-wide column tiles, partial last tiles, pre-reduced partial tables)."""
+    from yolo_v1_amd import _lib, ops
+    shapes = []
+    for H, nf, nl in ((112, 64, 6), (56, 128, 12), (28, 256, 24), (14, 512, 16)):
+        shapes += [(H, nf + 32 * i, 128, True) for i in range(nl)]
+        shapes.append((H, nf + 32 * nl, (nf + 32 * nl) // 2, False))
+    N = 64
+    gen = torch.Generator(device=DEV).manual_seed(1234)
+    seen = {}
+    for (H, cin, cout, acc) in shapes:
+        x = ops.Act((torch.randn(N, H, H, cin, generator=gen, device=DEV) * 1.3 + 0.4).to(torch.bfloat16))
+        bn = torch.nn.BatchNorm2d(cin).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(cin, generator=gen, device=DEV) + 0.5)
+            bn.bias.copy_(torch.randn(cin, generator=gen, device=DEV) * 0.3)
+        st = ops.bn_finalize(ops.bn_stats(x), x.npix, bn)
+        param = torch.nn.Parameter((torch.randn(cout, cin, 1, 1, generator=gen, device=DEV) * (2.0 / cin) ** 0.5)
+                                   .contiguous(memory_format=torch.channels_last))
+        w = ops.ConvWeights(param, 1, 1, 0)
+        w.refresh()
+        dy = ops.Act((torch.randn(N, H, H, cout, generator=gen, device=DEV) * 0.05).to(torch.bfloat16))
+        old = (torch.randn(N, H, H, cin, generator=gen, device=DEV) * 0.02).to(torch.bfloat16)
+        G_ref = ops.Act(old.clone() if acc else torch.empty_like(old))
+        dt = ops.new_act(N, H, H, cin, DEV)
+        ops.conv_dgrad(dy, w, dt)
+        dg_ref, db_ref = ops.bn_backward(dt, x, st, bn, G_ref, 2, accumulate=acc)
+        G = ops.Act(old.clone() if acc else torch.empty_like(old))
+        K = torch.zeros((2, cin), dtype=torch.float32, device=DEV)
+        part = ops.conv_dgrad_bn_deferred(dy, w, G, x, st, accumulate=acc)
+        cfg = ";".join(_lib.last_config())
+        dg, db = ops.bn_bwd_finalize_deferred(part, x.npix, bn, st, K, accumulate=True)
+        ops.bn_deferred_fix(G, x, K)
+        seen[cfg] = seen.get(cfg, 0) + 1
+        sb, sg = float(db_ref.abs().max()) + 1e-12, float(dg_ref.abs().max()) + 1e-12
+        assert "bn-deferred" in cfg, (H, cin, cfg)
+        assert float((db - db_ref).abs().max()) <= 1e-4 * sb, (H, cin, float((db - db_ref).abs().max()) / sb)
+        assert float((dg - dg_ref).abs().max()) <= 1e-3 * sg, (H, cin, float((dg - dg_ref).abs().max()) / sg)
+        assert _rel(G.t, G_ref.t) <= 5e-3, (H, cin, _rel(G.t, G_ref.t))
+        del x, dy, old, G, G_ref, dt
+    print("\ntemplates over the %d shapes: %s" % (len(shapes), seen))
+
+
 def test_corrections_of_several_layers_sum_before_one_fix():
     """Three BatchNorms over nested channel ranges of ONE feature tensor (the dense block's pattern): coefficients add up
     in K and one fix per channel range reproduces three reference backward passes."""
