@@ -10,7 +10,9 @@ Pieces, each against a direct restatement:
   * the whole replacement (T GEMM, coefficients, operand build, data gradient, dW3 assembly) against the pass-based
     BatchNorm-3 backward + conv3 dgrad/wgrad on the SAME tensors: dbeta 2e-3, dgamma 5e-3 (of the largest; measured 2.6e-3), dz2 and dW3 rel-L2 <= 1e-2 -- the two
     paths differ by where bf16 rounding happens (dy3 is never rounded here; W' and Q are), 2-3e-3 on the CPU emulation
-    (tools/bn3_algebra_check.py);
+    (tools/bn3_algebra_check.py) -- and BOTH against fp64 arithmetic on the same bf16 operands, including the two shapes the
+    batch-64 step runs (layer1: M = 803 k pixels, layer2: 200 k): the algebra's dW3 / dgamma / dbeta are fp32-exact (<= 1e-5
+    asserted, 3-5e-7 measured), the pass-based dW3 carries dy3's bf16 rounding (2e-3 ... 3.3e-2 with M);
   * a ResNet-50 training step with and without the algebra: the loss identical (the forward is untouched), layer4 / layer5 /
     head gradients bit-identical (no algebra block above them), every other parameter gradient within rel-L2 1.5e-1 /
     cosine 0.99 (measured worst 8.2e-2 / 0.9967 at the stem: two valid bf16 roundings 3e-3 apart per block compound through
@@ -112,7 +114,8 @@ def _bits(mask, M, C):
     return (b & 1).bool().view(M, C)
 
 
-@pytest.mark.parametrize("N,H,p", [(8, 28, 64), (16, 28, 256)])
+@pytest.mark.parametrize("N,H,p", [(8, 28, 64), (16, 28, 256),
+                                   (64, 112, 64), (64, 56, 128)])     # the two shapes the batch-64 step runs it on (layer1, layer2)
 def test_bn3_algebra_matches_the_pass_based_backward(N, H, p):
     from yolo_v1_amd import ops
     C4 = 4 * p
@@ -147,12 +150,30 @@ def test_bn3_algebra_matches_the_pass_based_backward(N, H, p):
     side.join()
     torch.cuda.synchronize()
     scale_g = float(dg_ref.abs().max())
-    assert float((db - db_ref).abs().max()) <= 2e-3 * float(db_ref.abs().max()) + 1e-7
-    assert float((dg - dg_ref).abs().max()) <= 5e-3 * scale_g + 1e-7       # the passes read the bf16-ROUNDED y3, the algebra never rounds it
-    print("\np=%d @%d: dz2 rel-L2 %.2e, dW3 rel-L2 %.2e, dgamma max err / max %.2e" % (
-        p, H, _rel(dz2.t, dz2_ref.t), _rel(dW, dW_ref), float((dg - dg_ref).abs().max()) / scale_g))
-    assert _rel(dz2.t, dz2_ref.t) <= 1e-2
-    assert _rel(dW, dW_ref) <= 1e-2
+    # fp64 truth from the SAME bf16 operands (z2, the bf16 weight copy the forward multiplied with, the masked gradient):
+    # which of the two is closer to exact arithmetic (tools/bn3_algebra_truth.py prints the table)
+    Z, Wd, Gm = z2.t.view(M, p).double(), w3.fwd.view(C4, p).double(), gm.t.view(M, C4).double()
+    Y = Z @ Wd.t()
+    mu, isd = Y.mean(0), 1.0 / torch.sqrt(Y.var(0, unbiased=False) + 1e-5)
+    xh = (Y - mu) * isd
+    dbt, dgt = Gm.sum(0), (Gm * xh).sum(0)
+    dY = bn3.weight.detach().double() * isd * (Gm - dbt / M - xh * dgt / M)
+    dWt, dzt = dY.t() @ Z, dY @ Wd
+    rt = lambda a, b: float((a.double() - b).norm() / b.norm())
+    ea = (rt(dW.reshape(C4, p), dWt), rt(dg, dgt), rt(db, dbt), rt(dz2.t.view(M, p), dzt))
+    ep = (rt(dW_ref.reshape(C4, p), dWt), rt(dg_ref, dgt), rt(db_ref, dbt), rt(dz2_ref.t.view(M, p), dzt))
+    print("\np=%d @%d M=%d  rel-L2 against fp64 truth (dW3, dgamma, dbeta, dz2): algebra %.1e %.1e %.1e %.1e | passes %.1e %.1e "
+          "%.1e %.1e" % ((p, H, M) + ea + ep))
+    # the algebra never rounds dy3 to bf16: dW3 / dgamma / dbeta are fp32-exact (measured 3-5e-7 at every size), dz2 carries the
+    # one bf16 rounding of its store.  The pass-based dW3 / dgamma carry dy3's / y3's bf16 rounding: 2.2e-3 at M = 6 k,
+    # 1.0e-2 at M = 200 k, 3.3e-2 at M = 803 k (layer1 at batch 64) on this iid test gradient.
+    assert ea[0] <= 1e-5 and ea[1] <= 1e-5 and ea[2] <= 1e-5 and ea[3] <= 5e-3, ea
+    assert ep[3] <= 5e-3 and ep[2] <= 1e-5, ep
+    if M <= 20000:                                            # small maps: the two paths also agree with each other
+        assert float((db - db_ref).abs().max()) <= 2e-3 * float(db_ref.abs().max()) + 1e-7
+        assert float((dg - dg_ref).abs().max()) <= 5e-3 * scale_g + 1e-7   # the passes read the bf16-ROUNDED y3
+        assert _rel(dz2.t, dz2_ref.t) <= 1e-2
+        assert _rel(dW, dW_ref) <= 1e-2
 
 
 @pytest.mark.parametrize("N,H,cx,p,stride", [(8, 28, 64, 64, 1), (8, 56, 256, 128, 2)])
