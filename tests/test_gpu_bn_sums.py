@@ -142,7 +142,7 @@ def test_training_step_with_and_without_the_fused_reduction(kind):
             worst = (n, r)
         # the masked gradient is bit-identical; dgamma / dbeta (and with them k2, k3) move by fp32 summation order, which
         # flips a bf16 rounding here and there downstream
-        if not (r <= 5e-2 and c >= 0.995):
+        if not (r <= 8e-2 and c >= 0.995):                 # measured worst 4.2e-2 (ResNet bn1.bias), 3.5e-3 (DenseNet)
             bad.append((n, r, c))
     print("\nworst rel-L2 with / without the fused reduction (%s): %s %.3g" % ((kind,) + worst))
     assert not bad, bad[:12]
