@@ -254,14 +254,16 @@ int yv1_bn3_dw(const float* T, const float* G, const float* sz_partials, int row
  * norm1 -> relu1 -> conv1 over the concatenated features (OriginDenseNet.py:22-27,:32-36) and the transitions' norm -> relu ->
  * conv (:50-52).  dx = a*d - a*mean(d) - a*xhat*mean(d*xhat) with d the ReLU-masked gradient at the BatchNorm output and
  * a = gamma*invstd:  the first term is added by the data gradient's own epilogue (which also emits the two sums per pixel
- * tile: part [rows][2][Cin] = sum d, sum d*(x - mean)), the other two are affine in x per channel -- their coefficients of
- * every layer that normalises the same features are summed in KA / KB by yv1_bn_bwd_finalize_deferred (which also returns
- * dgamma / dbeta) and subtracted once by yv1_bn_deferred_fix before the gradient of those channels is consumed.  Replaces
+ * tile: part [rows][2][Cin] = sum d, sum d*(x - mean)), the other two are affine in x per channel: yv1_bn_bwd_finalize_deferred
+ * returns their coefficients KA / KB (and dgamma / dbeta); they are subtracted by the NEXT data gradient into the same
+ * buffer (pend_a / pend_b, same epilogue pass) or, for channels no later launch covers, by yv1_bn_deferred_fix before the
+ * gradient of those channels is consumed -- the buffer never holds more than one layer's uncorrected term.  Replaces
  * yv1_conv2d_dgrad_nhwc_bf16 + yv1_bn_bwd_reduce + yv1_bn_bwd_finalize + yv1_bn_bwd_apply(accumulate) there; the masked
  * gradient tensor is never stored.  1x1, stride 1, pad 0; Cout (the convolution's output channels) % 64 == 0. */
 int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx, int Cin,
                                            int Cout, int lddy, const void* x, int ldx, const float* scale, const float* shift,
-                                           const float* mean, int accumulate, float* part, int wt_rows, yv1_stream_t stream);
+                                           const float* mean, int accumulate, float* part, int wt_rows, const float* pend_a,
+                                           const float* pend_b, yv1_stream_t stream);   /* pend_*: nullable, see below */
 int yv1_conv2d_dgrad_bn_deferred_rows(int M, int Cin, int Cout, int wt_rows);   /* wt_rows: readable (zero-padded) rows of wt */
 int yv1_bn_bwd_finalize_deferred(const float* part, int rows, int C, float count, const float* gamma, const float* mean,
                                  const float* invstd, float* dgamma, float* dbeta, float* KA, float* KB, int accumulate,

@@ -3,9 +3,10 @@ against the sequence it replaces -- autograd of `conv1(relu1(norm1(cat(features)
 22-27,:32-36) and of `conv(relu(norm(x)))` in a _Transition (:50-52):
 
     reference path   dt = conv_dgrad(dy, w);  bn_backward(dt, x, st, mask_mode 2, accumulate) -> G, dgamma, dbeta
-    deferred path    part = conv_dgrad_bn_deferred(dy, w, G, x, st)   (G += scale * mask * dgrad in the epilogue)
-                     dgamma, dbeta = bn_bwd_finalize_deferred(part, ...) (+ correction coefficients into K)
-                     bn_deferred_fix(G, x, K)                            (G -= KA + KB * x)
+    deferred path    part = conv_dgrad_bn_deferred(dy, w, G, x, st[, pending])   (G += scale * mask * dgrad - pending
+                                                                                   correction, in the epilogue)
+                     dgamma, dbeta = bn_bwd_finalize_deferred(part, ...) (correction coefficients into K)
+                     bn_deferred_fix(G, x, K)                            (G -= KA + KB * x where no later launch does it)
 
 Both paths mask the SAME bf16-rounded data gradient and sum it in fp32, so dbeta / dgamma agree to summation order (1e-4 of
 the largest); G differs by where its bf16 roundings fall (the reference rounds a*d - k2 - k3*xhat + old once, the deferred
@@ -139,9 +140,11 @@ def test_every_densenet121_layer_shape_at_batch_64():
     print("\ntemplates over the %d shapes: %s" % (len(shapes), seen))
 
 
-def test_corrections_of_several_layers_sum_before_one_fix():
-    """Three BatchNorms over nested channel ranges of ONE feature tensor (the dense block's pattern): coefficients add up
-    in K and one fix per channel range reproduces three reference backward passes."""
+def test_nested_batchnorms_with_pending_corrections():
+    """Three BatchNorms over nested channel ranges of ONE feature tensor, in the executor's order (the dense block's
+    pattern, backbones/OriginDenseNet.py:layer_backward): each data gradient subtracts what the previous BatchNorm still owes
+    the channels it covers (``pending``), the finalize replaces the table with this layer's coefficients, the 32-channel slice
+    no later launch touches is fixed separately -- against three reference backward passes."""
     from yolo_v1_amd import ops
     N, H, ctot = 4, 28, 160
     g = torch.Generator().manual_seed(11)
@@ -149,7 +152,8 @@ def test_corrections_of_several_layers_sum_before_one_fix():
     buf = ops.Act(xt)
     G_ref = ops.Act(torch.zeros_like(xt))
     G = ops.Act(torch.zeros_like(xt))
-    K = torch.zeros((2, ctot), dtype=torch.float32, device=DEV)
+    K = torch.empty((2, ctot), dtype=torch.float32, device=DEV)
+    owed, prev = False, None
     for li, cin in enumerate((160, 128, 96)):
         xin = buf.window(0, cin)
         bn = torch.nn.BatchNorm2d(cin).to(DEV)
@@ -161,16 +165,17 @@ def test_corrections_of_several_layers_sum_before_one_fix():
                                    .contiguous(memory_format=torch.channels_last))
         w = ops.ConvWeights(param, 1, 1, 0)
         w.refresh()
-        dy = ops.Act((torch.randn(N, H, H, 128, generator=g) * 0.05).to(torch.bfloat16).to(DEV))
+        dy = ops.Act(((torch.randn(N, H, H, 128, generator=g) + 0.7) * 0.05).to(torch.bfloat16).to(DEV))   # not mean-free
         dt = ops.new_act(N, H, H, cin, DEV)
         ops.conv_dgrad(dy, w, dt)
         ops.bn_backward(dt, xin, st, bn, G_ref.window(0, cin), 2, accumulate=True)
-        part = ops.conv_dgrad_bn_deferred(dy, w, G.window(0, cin), xin, st, accumulate=True)
-        ops.bn_bwd_finalize_deferred(part, xin.npix, bn, st, K[:, :cin], accumulate=True)
-        # the slice [cin-32, cin) is complete now (the layer that made it comes next in a dense block): fix it, like
-        # layer_backward does before consuming it
-        ops.bn_deferred_fix(G.window(cin - 32, 32), buf.window(cin - 32, 32), K[:, cin - 32:cin])
-    ops.bn_deferred_fix(G.window(0, 64), buf.window(0, 64), K[:, :64])
+        if owed:                                  # the slice [cin, prev) is complete: nothing below touches it again
+            ops.bn_deferred_fix(G.window(cin, prev - cin), buf.window(cin, prev - cin), K[:, cin:prev])
+        part = ops.conv_dgrad_bn_deferred(dy, w, G.window(0, cin), xin, st, accumulate=True,
+                                          pending=K[:, :cin] if owed else None)
+        ops.bn_bwd_finalize_deferred(part, xin.npix, bn, st, K[:, :cin], accumulate=False)
+        owed, prev = True, cin
+    ops.bn_deferred_fix(G.window(0, prev), buf.window(0, prev), K[:, :prev])
     torch.cuda.synchronize()
     assert _rel(G.t, G_ref.t) <= 8e-3, _rel(G.t, G_ref.t)
 

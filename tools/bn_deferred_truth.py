@@ -20,8 +20,9 @@ xt = (torch.randn(N, H, H, ctot, generator=gen, device=DEV) * 1.1 + 0.3).to(torc
 buf = ops.Act(xt)
 M = buf.npix
 G_ref, G = ops.Act(torch.zeros_like(xt)), ops.Act(torch.zeros_like(xt))
-K = torch.zeros((2, ctot), dtype=torch.float32, device=DEV)
+K = torch.empty((2, ctot), dtype=torch.float32, device=DEV)
 Gt = torch.zeros(M, ctot, dtype=torch.float64, device=DEV)
+owed, prev = False, ctot
 for li in reversed(range(L)):
     cin = c0 + growth * li + growth          # this "layer" normalises everything produced so far
     cin = min(cin, ctot)
@@ -39,8 +40,11 @@ for li in reversed(range(L)):
     dt = ops.new_act(N, H, H, cin, DEV)
     ops.conv_dgrad(dy, w, dt)
     ops.bn_backward(dt, xin, st, bn, G_ref.window(0, cin), 2, accumulate=True)
-    part = ops.conv_dgrad_bn_deferred(dy, w, G.window(0, cin), xin, st, accumulate=True)
-    ops.bn_bwd_finalize_deferred(part, xin.npix, bn, st, K[:, :cin], accumulate=True)
+    if owed and prev > cin:                       # the executor's order (OriginDenseNet.layer_backward)
+        ops.bn_deferred_fix(G.window(cin, prev - cin), buf.window(cin, prev - cin), K[:, cin:prev])
+    part = ops.conv_dgrad_bn_deferred(dy, w, G.window(0, cin), xin, st, accumulate=True, pending=K[:, :cin] if owed else None)
+    ops.bn_bwd_finalize_deferred(part, xin.npix, bn, st, K[:, :cin], accumulate=False)
+    owed, prev = True, cin
     # truth
     X = xt.view(M, ctot)[:, :cin].double()
     Wd = w.fwd.view(128, cin).double()
@@ -51,7 +55,7 @@ for li in reversed(range(L)):
     D = D * mask
     xh = (X - mu) * isd
     Gt[:, :cin] += a * (D - D.mean(0) - xh * (D * xh).mean(0))
-ops.bn_deferred_fix(G, buf, K)
+ops.bn_deferred_fix(G.window(0, prev), buf.window(0, prev), K[:, :prev])
 torch.cuda.synchronize()
 rel = lambda t: float((t.view(M, ctot).double() - Gt).norm() / Gt.norm())
 unc = float((G.t.view(M, ctot).double()).norm())

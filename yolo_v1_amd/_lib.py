@@ -65,7 +65,7 @@ SIGNATURES = {
     "yv1_bn3_dw": (c_i, [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yv1_conv2d_stats_rows": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "yv1_conv2d_dgrad_bn_deferred_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p,
-                                                     c_i, c_p, c_i, c_p]),
+                                                     c_i, c_p, c_i, c_p, c_p, c_p]),
     "yv1_conv2d_dgrad_bn_deferred_rows": (c_i, [c_i, c_i, c_i, c_i]),
     "yv1_conv2d_dgrad_bn_sums_nhwc_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p,
                                                  c_p, c_p, c_p]),

@@ -120,8 +120,9 @@ class DenseNet(HipBackbone):
         """Backward of one _DenseLayer: ``G`` holds the gradient of the block buffer; the layer's own slice is complete
         (every later layer has added to it), its input gradient is accumulated into G[..., :cin].
         ``K`` ([2][Ctot] fp32, ops.BN_DEFERRED): norm1's backward is deferred -- conv1's data gradient adds scale * masked
-        gradient to G in its epilogue, the mean terms of every BatchNorm over a channel are summed in K and subtracted from
-        that channel's gradient here, right before it is consumed (``owed``: a later layer has put something into K)."""
+        gradient to G in its epilogue; the mean terms (affine in x per channel, coefficients in K) are subtracted by the NEXT
+        data gradient into G -- every layer covers all channels below it -- and, for this layer's own 32-channel slice, which
+        no later launch touches, here, right before it is consumed (``owed``: K holds something)."""
         (layer, cin, st1, t1, y1, st2, t2) = lrec
         dev = G.t.device
         N = G.N
@@ -142,10 +143,14 @@ class DenseNet(HipBackbone):
             grads[layer.norm2.weight], grads[layer.norm2.bias] = ops.bn_backward_from_sums(dt2, y1, st2, layer.norm2, dy1, part2)
         mk = side.mark()
         if K is not None:
-            part = ops.conv_dgrad_bn_deferred(dy1, w1, G.window(0, cin), buf.window(0, cin), st1, accumulate=True)
+            # K[:, :cin] holds what the BatchNorm handled by the previous launch into G (the layer above, or the transition)
+            # still owes these channels: subtracted by this launch, then replaced by this layer's own coefficients
+            pend = ops.BN_DEFERRED_PENDING
+            part = ops.conv_dgrad_bn_deferred(dy1, w1, G.window(0, cin), buf.window(0, cin), st1, accumulate=True,
+                                              pending=K[:, :cin] if (owed and pend) else None)
             grads[layer.conv1.weight] = ops.conv_wgrad(t1, dy1, w1, side, after=mk)
             grads[layer.norm1.weight], grads[layer.norm1.bias] = ops.bn_bwd_finalize_deferred(
-                part, buf.npix, layer.norm1, st1, K[:, :cin], accumulate=True)
+                part, buf.npix, layer.norm1, st1, K[:, :cin], accumulate=owed and not pend)
         else:
             dt1 = ops.new_act(N, t1.H, t1.W, cin, dev)
             ops.conv_dgrad(dy1, w1, dt1)
@@ -294,7 +299,7 @@ class DenseNet(HipBackbone):
             if stage[0] == "block":
                 _, buf, lrecs, nf = stage
                 if deferred and K is None:
-                    K = torch.zeros((2, buf.C), dtype=torch.float32, device=dev)
+                    K = torch.empty((2, buf.C), dtype=torch.float32, device=dev)     # written before it is read (owed)
                 for lrec in reversed(lrecs):
                     self.layer_backward(lrec, buf, G, grads, side, K, owed)
                     owed = owed or K is not None

@@ -80,6 +80,8 @@ struct ConvArgs {
   const float* dbmean = nullptr;
   float* dbpart = nullptr;             // [MT][2][Cout]: sum(d), sum(d * (x - mean)) with d = masked gradient (bf16 values)
   int db_wt_rows = 0;                  // readable rows of W (zero beyond Cout): lets the last column tile reach past Cout
+  const float* dbpa = nullptr;         // optional PENDING correction of the destination (deferred form): dx -= dbpa[c] + dbpb[c] * x,
+  const float* dbpb = nullptr;         //   the affine term the BatchNorm handled by the PREVIOUS launch into this buffer still owes
   int db_unit = 0;                     // 1: store the masked gradient itself (not scale * masked): the BatchNorm backward's
   const float* dbis = nullptr;         //    apply pass follows; dbis: invstd -- the second sum is then sum(d * xhat)
   int M;
@@ -166,6 +168,22 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
       }
       __builtin_amdgcn_sched_barrier(0);   // one 32x32 block at a time: keeps the accumulator->VGPR copies short-lived
     }
+  // DB epilogue: the tile's per-channel vectors (scale, shift, mean, pending A / B) go through LDS once per workgroup, behind
+  // the statistics area -- fetched per thread they were 160 B x 256 threads = 40 KB of L2 requests per tile, as much as the
+  // tile's own operands (the deferred data gradient ran 298 us against a 177 us byte bound at 112x112, 13-25 % more with the
+  // pending vectors)
+  float* dbv = reinterpret_cast<float*>(smem + BM * EPI_PITCH + WM * 2 * BN * 4);     // [5][BN]
+  if constexpr (DB) {
+    if (tid < BN) {
+      const int c = n0 + tid;
+      const bool ok = c < a.Cout;
+      dbv[0 * BN + tid] = ok ? a.dbscale[c] : 0.f;
+      dbv[1 * BN + tid] = ok ? a.dbshift[c] : 0.f;
+      dbv[2 * BN + tid] = ok ? a.dbmean[c] : 0.f;
+      dbv[3 * BN + tid] = (ok && a.dbpa) ? a.dbpa[c] : 0.f;
+      dbv[4 * BN + tid] = (ok && a.dbpa) ? a.dbpb[c] : 0.f;
+    }
+  }
   __syncthreads();
 
   if (a.stats && tid < BN) {
@@ -189,11 +207,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     constexpr int RG = NTH / OCPR;
     const int cc = tid % OCPR, rg = tid / OCPR;
     const bool cok = n0 + cc * 8 < a.Cout;                 // the last column tile may reach past Cout (zero weight rows)
-    float sc[8], sh[8], mu[8], s1[8], s2[8];
+    float sc[8], sh[8], mu[8], s1[8], s2[8], pa[8], pb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      sc[k] = cok ? a.dbscale[n0 + cc * 8 + k] : 0.f; sh[k] = cok ? a.dbshift[n0 + cc * 8 + k] : 0.f;
-      mu[k] = cok ? a.dbmean[n0 + cc * 8 + k] : 0.f;
+      sc[k] = dbv[0 * BN + cc * 8 + k]; sh[k] = dbv[1 * BN + cc * 8 + k]; mu[k] = dbv[2 * BN + cc * 8 + k];
+      pa[k] = dbv[3 * BN + cc * 8 + k]; pb[k] = dbv[4 * BN + cc * 8 + k];
       s1[k] = 0.f; s2[k] = 0.f;
     }
     uint4 x_pre[OPASSES], old_pre[OPASSES];
@@ -222,8 +240,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
           const float dh = (xh * sc[2 * k + 1] + sh[2 * k + 1]) > 0.f ? __uint_as_float(pv[k] & 0xffff0000u) : 0.f;
           s1[2 * k] += dl; s1[2 * k + 1] += dh;
           s2[2 * k] += dl * (xl - mu[2 * k]); s2[2 * k + 1] += dh * (xh - mu[2 * k + 1]);
-          res[k] = pack_bf16x2(__uint_as_float(po[k] << 16) + (a.db_unit ? dl : sc[2 * k] * dl),
-                               __uint_as_float(po[k] & 0xffff0000u) + (a.db_unit ? dh : sc[2 * k + 1] * dh));
+          res[k] = pack_bf16x2(__uint_as_float(po[k] << 16) + (a.db_unit ? dl : sc[2 * k] * dl) - (pa[2 * k] + pb[2 * k] * xl),
+                               __uint_as_float(po[k] & 0xffff0000u) + (a.db_unit ? dh : sc[2 * k + 1] * dh) -
+                                   (pa[2 * k + 1] + pb[2 * k + 1] * xh));
         }
         *reinterpret_cast<uint4*>(a.Y + (size_t)m * a.ldy + n0 + cc * 8) = make_uint4(res[0], res[1], res[2], res[3]);
       }
@@ -1584,6 +1603,7 @@ int launch_dma(ConvArgs& a, hipStream_t stream) {
   constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
   constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
   static_assert(!DB || LDS >= (size_t)2 * 8 * WM * WN * 64 * 4, "the deferred-BatchNorm sums reduce through 2 x [RG][BN] floats");
+  static_assert(!DB || LDS >= (size_t)EPI + 5 * BN * 4, "the DB epilogue's per-channel vectors sit behind the statistics area");
   a.MT = (a.M + BM - 1) / BM;
   a.NT = DB ? (a.Cout + BN - 1) / BN : a.Cout / BN;       // DB: a partial last column tile (guarded epilogue, zero weight rows)
   auto kern = k_conv_dma<BM, BN, BK, WM, WN, NST, DB>;
@@ -1606,6 +1626,7 @@ int launch_h3(ConvArgs& a, hipStream_t stream) {
   constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
   constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
   static_assert(!DB || LDS >= (size_t)2 * 8 * 256 * 4, "the BatchNorm-backward sums reduce through 2 x [RG][BN] floats");
+  static_assert(!DB || LDS >= (size_t)EPI + 5 * BN * 4, "the DB epilogue's per-channel vectors sit behind the statistics area");
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
   auto kern = k_conv_h3<BM, BN, BK, WM, WN, NST, DB>;
@@ -2131,8 +2152,11 @@ extern "C" int yv1_conv2d_dgrad_out_nhwc_bf16(const void* dy, const void* wt, vo
 //     dx = (accumulate ? dx : 0) + scale * d                              (bf16, one rounding)
 //     part[tile][0][c] = sum_pixels d,  part[tile][1][c] = sum_pixels d * (x - mean[c])
 // What the BatchNorm backward subtracts from it -- scale * (mean(d) + xhat * mean(d * xhat)), an affine function of x per
-// channel -- is accumulated as coefficients by yv1_bn_bwd_finalize_deferred and applied once by yv1_bn_deferred_fix before the
-// gradient of those channels is consumed.  The stand-alone reduce and apply passes and the stored d tensor disappear.
+// channel -- comes out of yv1_bn_bwd_finalize_deferred as coefficients (A, B) and is applied LATE: by the next launch of this
+// entry into the same buffer (pend_a / pend_b: dx -= A + B * x in the same epilogue pass -- in a dense block every layer's
+// data gradient covers all channels below it, so the buffer never holds more than one uncorrected term) and, for the channels
+// no later launch touches, by yv1_bn_deferred_fix before they are consumed.  The stand-alone reduce and apply passes and the
+// stored d tensor disappear.
 // x: the BatchNorm input [N,IH,IW,*] (pixel stride ldx), scale/shift/mean: its forward coefficients [Cin]; Cout (the
 // convolution's output channels = GEMM K) must be a multiple of 64.  part: [yv1_conv2d_dgrad_bn_deferred_rows()][2][Cin].
 // wt_rows: rows of wt ([wt_rows][Cout] bf16) that may be read, >= Cin and ZERO beyond Cin -- padded to a multiple of 128 the
@@ -2140,9 +2164,11 @@ extern "C" int yv1_conv2d_dgrad_out_nhwc_bf16(const void* dy, const void* wt, vo
 extern "C" int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void* wt, void* dx, int N, int IH, int IW, int lddx,
                                                       int Cin, int Cout, int lddy, const void* x, int ldx, const float* scale,
                                                       const float* shift, const float* mean, int accumulate, float* part,
-                                                      int wt_rows, hipStream_t stream) {
+                                                      int wt_rows, const float* pend_a, const float* pend_b,
+                                                      hipStream_t stream) {
   yv1_cfg_reset();
   if (!dy || !wt || !dx || !x || !scale || !shift || !mean || !part || N <= 0 || wt_rows < Cin) return YV1_ERR_BAD_ARG;
+  if ((pend_a == nullptr) != (pend_b == nullptr) || (pend_a && !accumulate)) return YV1_ERR_BAD_ARG;
   if (Cout % 64 || Cin % 32 || ldx % 8 || lddx % 8) return YV1_ERR_UNSUPPORTED;
   ConvArgs a;
   a.X = (const bf16_t*)dy; a.W = (const bf16_t*)wt; a.Y = (bf16_t*)dx;
@@ -2154,7 +2180,7 @@ extern "C" int yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(const void* dy, const void
   a.ah = 1; a.bh = 0; a.ch = 0; a.aw = 1; a.bw = 0; a.cw = 0; a.log2d = 0;
   a.M = N * IH * IW;
   a.DBX = (const bf16_t*)x; a.lddbx = ldx; a.dbscale = scale; a.dbshift = shift; a.dbmean = mean; a.dbpart = part;
-  a.db_wt_rows = wt_rows;
+  a.db_wt_rows = wt_rows; a.dbpa = pend_a; a.dbpb = pend_b;
   return dispatch(a, stream);
 }
 

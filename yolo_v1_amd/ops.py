@@ -916,12 +916,16 @@ def bn_backward(dz, y, st, bn, dy, mask_mode, z=None, dres=None, accumulate=Fals
 # a pointwise convolution -- the reduction-free term rides in the data gradient's epilogue, the rest is summed as per-channel
 # coefficients and subtracted once per channel (0 = the dgrad + reduce + finalize + apply sequence)
 BN_DEFERRED = _os.environ.get("YV1_BN_DEFERRED", "1") != "0"
+# corrections applied by the NEXT data gradient into the buffer (one uncorrected term at a time) instead of summed up and
+# applied once per channel slice (0: the first form of the round -- same launches, lower precision)
+BN_DEFERRED_PENDING = _os.environ.get("YV1_BN_DEFERRED_PENDING", "1") != "0"
 
 
-def conv_dgrad_bn_deferred(dy, w, dx, x, st, accumulate=True):
+def conv_dgrad_bn_deferred(dy, w, dx, x, st, accumulate=True, pending=None):
     """dx (+)= scale * mask * conv_transpose(dy, w) for the 1x1 stride-1 convolution ``w`` whose input was relu(bn(x)) with the
     TRAINING-mode BNState ``st`` (mask = scale*x + shift > 0); returns the partial sums [rows][2][C] of the masked gradient
-    that bn_bwd_finalize_deferred turns into dgamma / dbeta and the correction coefficients."""
+    that bn_bwd_finalize_deferred turns into dgamma / dbeta and the correction coefficients.  ``pending`` ([2][C] rows KA, KB):
+    the correction the PREVIOUS launch into ``dx`` still owes these channels, subtracted in the same pass."""
     if w.k != 1 or w.stride != 1 or w.pad != 0:
         raise ValueError("conv_dgrad_bn_deferred: 1x1 stride-1 pad-0 convolution only")
     if (x.N, x.H, x.W, x.C) != (dx.N, dx.H, dx.W, dx.C) or x.C != w.Ipad:
@@ -933,7 +937,8 @@ def conv_dgrad_bn_deferred(dy, w, dx, x, st, accumulate=True):
     part = _f32(rows * 2 * dx.C, dev)
     check(L.yv1_conv2d_dgrad_bn_deferred_nhwc_bf16(dy.p, ptr(w.tr), dx.p, dx.N, dx.H, dx.W, dx.ld, w.Ipad, w.Opad, dy.ld, x.p,
                                                    x.ld, ptr(st.scale), ptr(st.shift), ptr(st.mean), 1 if accumulate else 0,
-                                                   ptr(part), wt_rows, stream_ptr(dev)),
+                                                   ptr(part), wt_rows, ptr(pending[0]) if pending is not None else None,
+                                                   ptr(pending[1]) if pending is not None else None, stream_ptr(dev)),
           "yv1_conv2d_dgrad_bn_deferred_nhwc_bf16")
     return part.view(rows, 2, dx.C)
 
