@@ -49,15 +49,29 @@ __global__ void __launch_bounds__(1024) k_bn_bwd_finalize_deferred(const float* 
   }
 }
 
-// g[m][c] -= KA[c] + KB[c] * x[m][c] over a C-channel window (C % 8 == 0) of two NHWC bf16 tensors
+// g[m][c] -= KA[c] + KB[c] * x[m][c] over a C-channel window (C % 8 == 0) of two NHWC bf16 tensors.
+// FIXED: the grid stride is a multiple of the chunks per pixel, so a thread keeps its 8 channels -- their coefficients are
+// loaded once, not per element (they were 64 B of loads beside 32 B of data).
+template <bool FIXED>
 __global__ void __launch_bounds__(256) k_bn_deferred_fix(bf16_t* __restrict__ g, int ldg, const bf16_t* __restrict__ x, int ldx,
                                                          const float* __restrict__ KA, const float* __restrict__ KB,
                                                          long long npix, int C) {
   const int cpr = C >> 3;
   const long long total = npix * cpr;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  float ka[8], kb[8];
+  if (FIXED) {
+    const int c8 = (int)(i0 % cpr) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ka[k] = KA[c8 + k]; kb[k] = KB[c8 + k]; }
+  }
+  for (long long i = i0; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long m = i / cpr;
     const int c8 = (int)(i - m * cpr) * 8;
+    if (!FIXED) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { ka[k] = KA[c8 + k]; kb[k] = KB[c8 + k]; }
+    }
     const uint4 gv = *reinterpret_cast<const uint4*>(g + m * ldg + c8);
     const uint4 xv = *reinterpret_cast<const uint4*>(x + m * ldx + c8);
     const unsigned* pg = reinterpret_cast<const unsigned*>(&gv);
@@ -65,9 +79,8 @@ __global__ void __launch_bounds__(256) k_bn_deferred_fix(bf16_t* __restrict__ g,
     unsigned res[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float lo = __uint_as_float(pg[k] << 16) - (KA[c8 + 2 * k] + KB[c8 + 2 * k] * __uint_as_float(px[k] << 16));
-      const float hi = __uint_as_float(pg[k] & 0xffff0000u) -
-                       (KA[c8 + 2 * k + 1] + KB[c8 + 2 * k + 1] * __uint_as_float(px[k] & 0xffff0000u));
+      const float lo = __uint_as_float(pg[k] << 16) - (ka[2 * k] + kb[2 * k] * __uint_as_float(px[k] << 16));
+      const float hi = __uint_as_float(pg[k] & 0xffff0000u) - (ka[2 * k + 1] + kb[2 * k + 1] * __uint_as_float(px[k] & 0xffff0000u));
       res[k] = pack_bf16x2(lo, hi);
     }
     *reinterpret_cast<uint4*>(g + m * ldg + c8) = make_uint4(res[0], res[1], res[2], res[3]);
@@ -97,8 +110,12 @@ extern "C" int yv1_bn_deferred_fix(void* g, int ldg, const void* x, int ldx, con
   const long long total = npix * (C / 8);
   long long blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(k_bn_deferred_fix, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16_t*)g, ldg, (const bf16_t*)x, ldx, KA,
-                     KB, npix, C);
+  if ((blocks * 256) % (C / 8) == 0)
+    hipLaunchKernelGGL(k_bn_deferred_fix<true>, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16_t*)g, ldg, (const bf16_t*)x,
+                       ldx, KA, KB, npix, C);
+  else
+    hipLaunchKernelGGL(k_bn_deferred_fix<false>, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16_t*)g, ldg, (const bf16_t*)x,
+                       ldx, KA, KB, npix, C);
   YV1_LAUNCH_CHECK();
   return YV1_OK;
 }
