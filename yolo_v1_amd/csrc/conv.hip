@@ -107,7 +107,7 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // Shared epilogue of the GEMM kernels: BatchNorm statistic partials from the fp32 accumulators, DPP lane swap +
 // packed rounding into a bf16 LDS tile, full-line stores (optionally accumulating / adding the masked shortcut
 // gradient).  The caller has finished its last LDS read (barrier) before the tile overwrites the staging buffers.
-template <int BM, int BN, int WM, int WN, bool DB = false>
+template <int BM, int BN, int WM, int WN, bool DB = false, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const ConvArgs& a,
                                               unsigned char* smem, int m0, int n0, int mt) {
   constexpr int NTH = WM * WN * 64;
@@ -116,6 +116,82 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, lh = lane >> 5;
+  // ---- DB epilogue: its operands (the BatchNorm input x and the destination's old values) are requested HERE, before the
+  // accumulators go through LDS -- their latency runs under epilogue 2 and its barrier instead of after it
+  constexpr int DB_OCPR = BN / 8, DB_PASSES = (BM * DB_OCPR + NTH - 1) / NTH, DB_RG = NTH / DB_OCPR;
+  uint4 x_pre[DB ? DB_PASSES : 1], old_pre[DB ? DB_PASSES : 1];
+  if constexpr (DB) {
+    const int cc = tid % DB_OCPR, rg = tid / DB_OCPR;
+    const bool cok = n0 + cc * 8 < a.Cout;
+#pragma unroll
+    for (int i = 0; i < DB_PASSES; ++i) {
+      const int row = rg + i * DB_RG, m = m0 + row;
+      x_pre[i] = make_uint4(0u, 0u, 0u, 0u); old_pre[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (cok && row < BM && m < a.M) {
+        x_pre[i] = *reinterpret_cast<const uint4*>(a.DBX + (size_t)m * a.lddbx + n0 + cc * 8);
+        if (a.accumulate) old_pre[i] = *reinterpret_cast<const uint4*>(a.Y + (size_t)m * a.ldy + n0 + cc * 8);
+      }
+    }
+  }
+  // ---- generic epilogue operands (shortcut gradient + masks, or the destination's old values): with PRE (k_conv_dma: one tile
+  // per workgroup, nothing else to overlap with) they are requested before the accumulators go through LDS, like the DB ones
+  constexpr int G_OCPR = BN / 8, G_PASSES = (BM * G_OCPR + NTH - 1) / NTH;
+  uint4 as_pre[G_PASSES];
+  unsigned am_pre[G_PASSES], om_pre[G_PASSES];
+  auto prefetch_generic = [&]() {
+    if (a.OM) {
+  #pragma unroll
+      for (int i = 0; i < G_PASSES; ++i) {
+        const int idx = tid + i * NTH;
+        const int row = idx / G_OCPR, cc = idx - row * G_OCPR;
+        const int m = m0 + row;
+        om_pre[i] = 0xffu;
+        if (row < BM && m < a.M) {
+          size_t dp = (size_t)m;
+          if (a.os != 1) {
+            const int pq = a.P * a.Q;
+            const int n = m / pq, rem = m - n * pq;
+            const int p = rem / a.Q, q = rem - p * a.Q;
+            dp = (size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0;
+          }
+          om_pre[i] = a.OM[dp * a.ldom + ((n0 + cc * 8) >> 3)];
+        }
+      }
+    }
+    if (a.AS) {
+  #pragma unroll
+      for (int i = 0; i < G_PASSES; ++i) {
+        const int idx = tid + i * NTH;
+        const int row = idx / G_OCPR, cc = idx - row * G_OCPR;
+        const int m = m0 + row;
+        if (row < BM && m < a.M) {
+          as_pre[i] = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + n0 + cc * 8);
+          am_pre[i] = a.AM ? a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)] : 0xffu;     // no mask: AS is added as it is
+        }
+      }
+    } else if (a.accumulate) {                 // the destination's old values, likewise (AS and accumulate are never combined)
+  #pragma unroll
+      for (int i = 0; i < G_PASSES; ++i) {
+        const int idx = tid + i * NTH;
+        const int row = idx / G_OCPR, cc = idx - row * G_OCPR;
+        const int m = m0 + row;
+        if (row < BM && m < a.M) {
+          size_t off;
+          if (a.os == 1) {
+            off = (size_t)m * a.ldy + n0 + cc * 8;
+          } else {
+            const int pq = a.P * a.Q;
+            const int n = m / pq, rem = m - n * pq;
+            const int p = rem / a.Q, q = rem - p * a.Q;
+            off = ((size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0) * a.ldy + n0 + cc * 8;
+          }
+          as_pre[i] = *reinterpret_cast<const uint4*>(a.Y + off);
+        }
+      }
+    }
+  };
+  const bool pre_now = PRE && !DB && !(a.dbg & 4);          // YV1_CONV_DBG bit 2 (tuning): request them after the barrier, as before
+  if (pre_now) prefetch_generic();
   // ---- epilogue 1: BatchNorm batch statistics from the fp32 accumulators
   // C/D layout of 32x32: col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel)
   float* red = reinterpret_cast<float*>(smem + BM * EPI_PITCH);   // [WM][2][BN] floats, after the epilogue tile
@@ -207,23 +283,25 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     constexpr int RG = NTH / OCPR;
     const int cc = tid % OCPR, rg = tid / OCPR;
     const bool cok = n0 + cc * 8 < a.Cout;                 // the last column tile may reach past Cout (zero weight rows)
-    float sc[8], sh[8], mu[8], s1[8], s2[8], pa[8], pb[8];
+    // scale / shift stay in registers (every element needs them twice); the pending vectors are re-read from LDS per pass
+    // and the mean enters once, at the end (sum d*(x - mu) = sum d*x - mu * sum d over this thread's <= 8 rows): 24 VGPRs
+    // less, which is what lets the 128x64 form run five workgroups per CU
+    float sc[8], sh[8], s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      sc[k] = dbv[0 * BN + cc * 8 + k]; sh[k] = dbv[1 * BN + cc * 8 + k]; mu[k] = dbv[2 * BN + cc * 8 + k];
-      pa[k] = dbv[3 * BN + cc * 8 + k]; pb[k] = dbv[4 * BN + cc * 8 + k];
+      sc[k] = dbv[0 * BN + cc * 8 + k]; sh[k] = dbv[1 * BN + cc * 8 + k];
       s1[k] = 0.f; s2[k] = 0.f;
     }
-    uint4 x_pre[OPASSES], old_pre[OPASSES];
+    const bool pend = a.dbpa != nullptr;
+    // 128-wide tiles (eight store passes, 168 VGPRs allowed): the pending vectors in registers after all -- re-read per pass
+    // they cost that form 10 % (314 -> 344 us at 112x112, Cin 256)
+    constexpr bool PREG = BN >= 128;
+    float pa[PREG ? 8 : 1], pb[PREG ? 8 : 1];
+    if constexpr (PREG) {
 #pragma unroll
-    for (int i = 0; i < OPASSES; ++i) {
-      const int row = rg + i * RG, m = m0 + row;
-      x_pre[i] = make_uint4(0u, 0u, 0u, 0u); old_pre[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (cok && row < BM && m < a.M) {
-        x_pre[i] = *reinterpret_cast<const uint4*>(a.DBX + (size_t)m * a.lddbx + n0 + cc * 8);
-        if (a.accumulate) old_pre[i] = *reinterpret_cast<const uint4*>(a.Y + (size_t)m * a.ldy + n0 + cc * 8);
-      }
+      for (int k = 0; k < 8; ++k) { pa[k] = dbv[3 * BN + cc * 8 + k]; pb[k] = dbv[4 * BN + cc * 8 + k]; }
     }
+    static_assert(OPASSES == DB_PASSES && RG == DB_RG, "the hoisted operand loads use the same pass geometry");
 #pragma unroll
     for (int i = 0; i < OPASSES; ++i) {
       const int row = rg + i * RG, m = m0 + row;
@@ -239,14 +317,23 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
           const float dl = (xl * sc[2 * k] + sh[2 * k]) > 0.f ? __uint_as_float(pv[k] << 16) : 0.f;
           const float dh = (xh * sc[2 * k + 1] + sh[2 * k + 1]) > 0.f ? __uint_as_float(pv[k] & 0xffff0000u) : 0.f;
           s1[2 * k] += dl; s1[2 * k + 1] += dh;
-          s2[2 * k] += dl * (xl - mu[2 * k]); s2[2 * k + 1] += dh * (xh - mu[2 * k + 1]);
-          res[k] = pack_bf16x2(__uint_as_float(po[k] << 16) + (a.db_unit ? dl : sc[2 * k] * dl) - (pa[2 * k] + pb[2 * k] * xl),
-                               __uint_as_float(po[k] & 0xffff0000u) + (a.db_unit ? dh : sc[2 * k + 1] * dh) -
-                                   (pa[2 * k + 1] + pb[2 * k + 1] * xh));
+          s2[2 * k] += dl * xl; s2[2 * k + 1] += dh * xh;
+          float ol = __uint_as_float(po[k] << 16) + (a.db_unit ? dl : sc[2 * k] * dl);
+          float oh = __uint_as_float(po[k] & 0xffff0000u) + (a.db_unit ? dh : sc[2 * k + 1] * dh);
+          if constexpr (PREG) {
+            ol -= pa[2 * k] + pb[2 * k] * xl;
+            oh -= pa[2 * k + 1] + pb[2 * k + 1] * xh;
+          } else if (pend) {
+            ol -= dbv[3 * BN + cc * 8 + 2 * k] + dbv[4 * BN + cc * 8 + 2 * k] * xl;
+            oh -= dbv[3 * BN + cc * 8 + 2 * k + 1] + dbv[4 * BN + cc * 8 + 2 * k + 1] * xh;
+          }
+          res[k] = pack_bf16x2(ol, oh);
         }
         *reinterpret_cast<uint4*>(a.Y + (size_t)m * a.ldy + n0 + cc * 8) = make_uint4(res[0], res[1], res[2], res[3]);
       }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s2[k] -= dbv[2 * BN + cc * 8 + k] * s1[k];       // sum d*(x - mu) of this thread's rows
     // fixed-order reduction over the RG threads that hold the same channel chunk; the epilogue tile is dead
     __syncthreads();
     float* r1 = reinterpret_cast<float*>(smem);            // [RG][BN]
@@ -266,61 +353,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
   }
   // shortcut-gradient operands of ALL passes up front: inside the loop every load sits behind the previous pass's store
   // (the compiler cannot prove Y and AS apart), i.e. one memory round trip per pass instead of one per tile
-  uint4 as_pre[OPASSES];
-  unsigned am_pre[OPASSES], om_pre[OPASSES];
   float gs[8];                                              // this thread's column sums (it keeps one 8-channel chunk: NTH % OCPR == 0)
 #pragma unroll
   for (int k = 0; k < 8; ++k) gs[k] = 0.f;
-  if (a.OM) {
-#pragma unroll
-    for (int i = 0; i < OPASSES; ++i) {
-      const int idx = tid + i * NTH;
-      const int row = idx / OCPR, cc = idx - row * OCPR;
-      const int m = m0 + row;
-      om_pre[i] = 0xffu;
-      if (row < BM && m < a.M) {
-        size_t dp = (size_t)m;
-        if (a.os != 1) {
-          const int pq = a.P * a.Q;
-          const int n = m / pq, rem = m - n * pq;
-          const int p = rem / a.Q, q = rem - p * a.Q;
-          dp = (size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0;
-        }
-        om_pre[i] = a.OM[dp * a.ldom + ((n0 + cc * 8) >> 3)];
-      }
-    }
-  }
-  if (a.AS) {
-#pragma unroll
-    for (int i = 0; i < OPASSES; ++i) {
-      const int idx = tid + i * NTH;
-      const int row = idx / OCPR, cc = idx - row * OCPR;
-      const int m = m0 + row;
-      if (row < BM && m < a.M) {
-        as_pre[i] = *reinterpret_cast<const uint4*>(a.AS + (size_t)m * a.ldas + n0 + cc * 8);
-        am_pre[i] = a.AM ? a.AM[(size_t)m * a.ldam + ((n0 + cc * 8) >> 3)] : 0xffu;     // no mask: AS is added as it is
-      }
-    }
-  } else if (a.accumulate) {                 // the destination's old values, likewise (AS and accumulate are never combined)
-#pragma unroll
-    for (int i = 0; i < OPASSES; ++i) {
-      const int idx = tid + i * NTH;
-      const int row = idx / OCPR, cc = idx - row * OCPR;
-      const int m = m0 + row;
-      if (row < BM && m < a.M) {
-        size_t off;
-        if (a.os == 1) {
-          off = (size_t)m * a.ldy + n0 + cc * 8;
-        } else {
-          const int pq = a.P * a.Q;
-          const int n = m / pq, rem = m - n * pq;
-          const int p = rem / a.Q, q = rem - p * a.Q;
-          off = ((size_t)(n * a.OH + p * a.os + a.oh0) * a.OW + q * a.os + a.ow0) * a.ldy + n0 + cc * 8;
-        }
-        as_pre[i] = *reinterpret_cast<const uint4*>(a.Y + off);
-      }
-    }
-  }
+  if (!pre_now) prefetch_generic();
 #pragma unroll
   for (int i = 0; i < OPASSES; ++i) {
     const int idx = tid + i * NTH;
@@ -599,7 +635,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NST, bool DB = false>
-__global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128 * 128 ? 3 : 2))) k_conv_dma(ConvArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (DB && BM == 128 && BN == 64 && NST == 2 ? 5 : (BM * BN <= 128 * 128 ? 3 : 2))))
+k_conv_dma(ConvArgs a) {
   constexpr int NTH = WM * WN * 64;
   constexpr int CPR = BK / 8;
   constexpr int RPP = NTH / CPR;                       // rows per pass (one pass = one DMA instruction per wave)
@@ -787,7 +824,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (BM == 256 ? 1 : (BM * BN <= 128
 #undef YV1_SET_TAP_D
 #undef YV1_ISSUE
   __syncthreads();                                     // all fragment reads done before the epilogue tile reuses LDS
-  conv_epilogue<BM, BN, WM, WN, DB>(acc, a, smem, m0, n0, mt);
+  conv_epilogue<BM, BN, WM, WN, DB, true>(acc, a, smem, m0, n0, mt);
 }
 
 // ---- 3x3 stride-1 convolutions: the three taps of a filter row share ONE A tile (round 3) -------------------------
@@ -1600,10 +1637,10 @@ template <int BM, int BN, int BK, int WM, int WN, int NST, bool DB = false>
 int launch_dma(ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int EPI_PITCH = (BN / 2 % 32 == 16) ? BN * 2 : BN * 2 + 64;
-  constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
+  constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4 + (DB ? 5 * BN * 4 : 0);     // DB: + the per-channel vectors
   constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
   static_assert(!DB || LDS >= (size_t)2 * 8 * WM * WN * 64 * 4, "the deferred-BatchNorm sums reduce through 2 x [RG][BN] floats");
-  static_assert(!DB || LDS >= (size_t)EPI + 5 * BN * 4, "the DB epilogue's per-channel vectors sit behind the statistics area");
+  static_assert(!DB || LDS >= (size_t)EPI, "the DB epilogue's per-channel vectors sit behind the statistics area");
   a.MT = (a.M + BM - 1) / BM;
   a.NT = DB ? (a.Cout + BN - 1) / BN : a.Cout / BN;       // DB: a partial last column tile (guarded epilogue, zero weight rows)
   auto kern = k_conv_dma<BM, BN, BK, WM, WN, NST, DB>;
@@ -1626,7 +1663,7 @@ int launch_h3(ConvArgs& a, hipStream_t stream) {
   constexpr int EPI = BM * EPI_PITCH + WM * 2 * BN * 4;
   constexpr size_t LDS = NST * STAGE > EPI ? NST * STAGE : EPI;
   static_assert(!DB || LDS >= (size_t)2 * 8 * 256 * 4, "the BatchNorm-backward sums reduce through 2 x [RG][BN] floats");
-  static_assert(!DB || LDS >= (size_t)EPI + 5 * BN * 4, "the DB epilogue's per-channel vectors sit behind the statistics area");
+  static_assert(!DB || LDS >= (size_t)EPI, "the DB epilogue's per-channel vectors sit behind the statistics area");
   a.MT = (a.M + BM - 1) / BM;
   a.NT = a.Cout / BN;
   auto kern = k_conv_h3<BM, BN, BK, WM, WN, NST, DB>;
@@ -1808,6 +1845,12 @@ ConvPlan plan_deferred(int M, int Cout, int Cin, int wt_rows) {
   return p;
 }
 
+bool db_two_stage() {
+  static int v = -1;
+  if (v < 0) v = env_int("YV1_DB_NST2", 1);               // tuning: 0 keeps the three-stage ring for the pointwise 128x64 DB form
+  return v != 0;
+}
+
 // Kernel of a data gradient with the BatchNorm-backward epilogue: the pointwise form (plan_deferred), k_conv_h3 where the
 // plain data gradient would run it (3x3 stride 1 with a 64-channel K block), else k_conv_dma with the 32-channel K step and
 // the three-stage ring -- the DB instantiations.  kind 0: not available for this shape (the caller keeps the separate passes).
@@ -1865,6 +1908,9 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     }
     if (p.kind != 1) return YV1_ERR_UNSUPPORTED;
     if (p.bm == 128 && p.bn == 128) return launch_dma<128, 128, 32, 2, 2, 3, true>(a, stream);
+    // pointwise 128x64: a two-stage ring (K is one or two hundred channels: the tile is all epilogue) in 27 KB of LDS and
+    // <= 102 VGPRs -- five workgroups per CU instead of four; the tile's latency chain, not bandwidth, bounds this kernel
+    if (p.bm == 128 && p.bn == 64 && a.R * a.S == 1 && db_two_stage()) return launch_dma<128, 64, 32, 2, 2, 2, true>(a, stream);
     if (p.bm == 128 && p.bn == 64) return launch_dma<128, 64, 32, 2, 2, 3, true>(a, stream);
     if (p.bm == 64 && p.bn == 64) return launch_dma<64, 64, 64, 2, 2, 3, true>(a, stream);
     if (p.bm == 128 && p.bn == 32) return launch_dma<128, 32, 64, 4, 1, 3, true>(a, stream);
