@@ -87,11 +87,12 @@ class HipBackbone(nn.Module):
         # tuned for kernels that run ALONE: the main chain has ended by the time the side stream gets to them
         # (measured, interleaved: 0 / 2 / 3 / 5 / 8 / 12 blocks -> 2909-2912 / 2920-2921 / 2919-2924 / 2918 / 2917-2921 / 2900 img/s)
         self.wgrad_wide_tail = int(os.environ.get("YV1_WGRAD_WIDE_TAIL", "3"))
-        # ResNet: bn1's / bn2's reduction pass inside conv2's / conv3's data gradient (ops.conv_dgrad_bn_sums).  Built, parity-
-        # tested, measured on the step (interleaved A/B): conv2 + conv3 2983 / 2986 -> 2967 / 2982 img/s, conv3 alone 2982 ->
-        # 2973 / 2977 -- the one-tile-per-workgroup kernels with the heavier epilogue cost what the p-wide reduction pass
-        # saves.  Off for ResNet; DenseNet's norm2 uses it (+0.5-1 %: its bottleneck tensors are read by five passes per layer).
-        self.bn_sums_conv2 = os.environ.get("YV1_BN_SUMS_CONV2", "0") == "1"
+        # ResNet: bn1's / bn2's reduction pass inside conv2's / conv3's data gradient (ops.conv_dgrad_bn_sums).  Measured on the
+        # step, interleaved A/B.  First build: conv2 + conv3 2983 / 2986 -> 2967 / 2982 img/s (slower).  After the epilogue work
+        # (per-channel vectors through LDS, operand loads ahead of the LDS staging): conv2 (k_conv_h3 with the epilogue)
+        # 3023 / 3023 / 3025 -> 3042 / 3039 / 3039 (+0.5 %): ON; conv3 (its plain form runs the persistent kernel, the fused
+        # one the one-tile-per-workgroup kernel) 3026 / 3022 vs 3024 / 3031: level, off.
+        self.bn_sums_conv2 = os.environ.get("YV1_BN_SUMS_CONV2", "1") != "0"
         self.bn_sums_conv3 = os.environ.get("YV1_BN_SUMS_CONV3", "0") == "1"
         self.bn_dual = os.environ.get("YV1_BN_DUAL", "1") != "0"         # projection blocks: bn3 + downsample BN backward in one pass
         self.fused_eval = os.environ.get("YV1_FUSED_EVAL", "1") != "0"   # eval(): BatchNorm folded into the conv epilogue
