@@ -395,10 +395,11 @@ import os as _os2
 # layer1-3 (256) 2926-2930 -- at 28x28 the two passes it removes (34 + 57 us) no longer cover T on the main stream, the
 # 256 x 256 x 1024 operand build and the 25 % longer data gradient.
 BN3_ALGEBRA_MAX_P = int(_os2.environ.get("YV1_BN3_ALGEBRA", "128"))
-# projection Bottlenecks too (bn3 and the downsample BatchNorm, both on the same masked gradient).  Built, parity-tested
-# (3.4e-3 against the dual passes) and measured LEVEL (3038-3051 vs 3036-3039 img/s): the dual passes already share their
-# reads of the gradient and the mask, and the algebra puts two T GEMMs in front of the data gradients.  Off by default.
-BN3_ALGEBRA_PROJ = _os2.environ.get("YV1_BN3_ALGEBRA_PROJ", "0") == "1"
+# projection Bottlenecks too (bn3 and the downsample BatchNorm, both on the same masked gradient).  Parity 3.4e-3 against the
+# dual passes.  First measurement: LEVEL (3038-3051 vs 3036-3039 img/s) -- two T GEMMs in front of the data gradients, and each
+# algebra call paid 227 us in k_bn3_dw's serial row loop.  After that loop was parallelised and the epilogue operands of the
+# masked-output data gradients were hoisted: 2984 / 2991 -> 3047 / 3053 img/s (+2.1 %, same box, interleaved): ON.
+BN3_ALGEBRA_PROJ = _os2.environ.get("YV1_BN3_ALGEBRA_PROJ", "1") != "0"
 
 
 def _gsum_rows_le32(gsum, dev):
